@@ -1,0 +1,122 @@
+"""ctypes front-end of oracle/libdcc_oracle.so (the CPU restatement in dcc_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never by the product package.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdcc_oracle.so")
+_lib = None
+
+
+class _Cfg(ctypes.Structure):
+    _fields_ = [("n_envs", ctypes.c_int32), ("n_agents", ctypes.c_int32), ("n_pois", ctypes.c_int32),
+                ("r_cover", ctypes.c_double), ("r_comm", ctypes.c_double),
+                ("comm_r_scale", ctypes.c_double), ("comm_force_scale", ctypes.c_double)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "dcc_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        vp = ctypes.c_void_p
+        L.dcc_oracle_create.restype = vp
+        L.dcc_oracle_create.argtypes = [ctypes.POINTER(_Cfg), vp]
+        L.dcc_oracle_destroy.argtypes = [vp]
+        L.dcc_oracle_reset.argtypes = [vp, vp]
+        L.dcc_oracle_get_state.argtypes = [vp] * 5
+        L.dcc_oracle_set_state.argtypes = [vp] * 5
+        L.dcc_oracle_step.argtypes = [vp, vp, ctypes.c_int] + [vp] * 12
+        L.dcc_oracle_obs_dim.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.dcc_oracle_rng_actions.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, vp]
+        L.dcc_oracle_rng_actions.restype = None
+        L.dcc_oracle_rollout_rng.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                             ctypes.c_int, vp, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def rng_actions(seed, step, n_envs, n_agents, env0=0, env_total=None):
+    out = np.empty((n_envs, n_agents, 2), np.float32)
+    lib().dcc_oracle_rng_actions(seed, step, n_envs, n_agents, env0, env_total or n_envs, _p(out))
+    return out
+
+
+class OracleEnv:
+    """Batched CPU env with the reference's semantics (float64 state).  step() returns a dict."""
+
+    def __init__(self, n_envs, n_agents, n_pois, poi_xy, r_cover=0.2, r_comm=0.4, comm_r_scale=0.95,
+                 comm_force_scale=0.0):
+        self.E, self.N, self.M = n_envs, n_agents, n_pois
+        self.D = lib().dcc_oracle_obs_dim(n_agents, n_pois)
+        poi = np.ascontiguousarray(poi_xy, np.float64)
+        assert poi.shape == (n_pois, 2)
+        cfg = _Cfg(n_envs, n_agents, n_pois, r_cover, r_comm, comm_r_scale, comm_force_scale)
+        self._h = lib().dcc_oracle_create(ctypes.byref(cfg), _p(poi))
+        if not self._h:
+            raise ValueError("dcc_oracle_create failed")
+
+    def close(self):
+        if self._h:
+            lib().dcc_oracle_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self):
+        obs = np.empty((self.E, self.N, self.D), np.float64)
+        lib().dcc_oracle_reset(self._h, _p(obs))
+        return obs
+
+    def get_state(self):
+        pos = np.empty((self.E, self.N, 2)); vel = np.empty((self.E, self.N, 2))
+        en = np.empty((self.E, self.M)); dn = np.empty((self.E, self.M), np.uint8)
+        lib().dcc_oracle_get_state(self._h, _p(pos), _p(vel), _p(en), _p(dn))
+        return dict(pos=pos, vel=vel, energy=en, done=dn)
+
+    def set_state(self, pos=None, vel=None, energy=None, done=None):
+        c = lambda a, t: None if a is None else np.ascontiguousarray(a, t)
+        pos, vel, energy, done = c(pos, np.float64), c(vel, np.float64), c(energy, np.float64), c(done, np.uint8)
+        lib().dcc_oracle_set_state(self._h, _p(pos), _p(vel), _p(energy), _p(done))
+
+    def step(self, actions, want_obs=True):
+        a = np.ascontiguousarray(actions)
+        assert a.shape == (self.E, self.N, 2) and a.dtype in (np.float32, np.float64)
+        E, N, M, D = self.E, self.N, self.M, self.D
+        out = dict(
+            obs=np.empty((E, N, D)) if want_obs else None, reward=np.empty(E), done=np.empty(E, np.uint8),
+            connect=np.empty(E, np.uint8), connect_s=np.empty(E, np.uint8), coverage=np.empty(E),
+            assign=np.empty((E, M), np.int32), pos_t=np.empty((E, N, 2)), vel_t=np.empty((E, N, 2)),
+            energy_t=np.empty((E, M)), done_t=np.empty((E, M), np.uint8), force_pairs=np.empty((E, N, 2), np.int32))
+        rc = lib().dcc_oracle_step(self._h, _p(a), int(a.dtype == np.float32), _p(out["obs"]), _p(out["reward"]),
+                                   _p(out["done"]), _p(out["connect"]), _p(out["connect_s"]), _p(out["coverage"]),
+                                   _p(out["assign"]), _p(out["pos_t"]), _p(out["vel_t"]), _p(out["energy_t"]),
+                                   _p(out["done_t"]), _p(out["force_pairs"]))
+        if rc != 0:
+            raise RuntimeError("dcc_oracle_step rc=%d" % rc)
+        return out
+
+    def rollout_rng(self, K, seed, step0=0, env0=0, env_total=None, want_obs_last=False):
+        E = self.E
+        rew = np.empty((K, E)); dn = np.empty((K, E), np.uint8); cov = np.empty((K, E))
+        obs = np.empty((E, self.N, self.D)) if want_obs_last else None
+        lib().dcc_oracle_rollout_rng(self._h, K, seed, step0, env0, env_total or E, _p(rew), _p(dn), _p(cov), _p(obs))
+        return dict(reward=rew, done=dn, coverage=cov, obs_last=obs)
