@@ -1,0 +1,733 @@
+// dcc_env.hip -- batched multi-agent coverage environment for MI355X (gfx950 / CDNA4).
+//
+// One environment per 64-lane wavefront, 4 wavefronts (4 envs) per workgroup:
+//   * lane i < N owns UAV i: pos/vel live in that lane's registers in float64 for all K fused
+//     steps and are mirrored into LDS (apos/avel) so that every lane can broadcast-read them;
+//   * lane l owns PoIs {l, l+64, ...} (PPL per lane): energy / done bits live in registers;
+//   * UAVxUAV adjacency: lane <-> (a,b) pair, one __ballot per 64 pairs gives adjacency rows as
+//     bitmasks; connectivity is a bitmask BFS driven by __ballot (the env is wave-uniform, so the
+//     connectivity-preserving force branch is a scalar branch, never divergent);
+//   * UAVxPoI distances, coverage count, min-distance reward and the PoI-assignment index are
+//     computed lane-per-PoI against the LDS-resident UAV positions, reduced with ballots /
+//     shuffles;
+//   * observations (91 % of the bytes) are produced into a per-wave LDS staging window in the
+//     reference's feature order and streamed to HBM as fully coalesced 16-byte-per-lane stores.
+//
+// Arithmetic follows the reference statement by statement in float64 (compiled with
+// -ffp-contract=off; the only fused multiply-add is the one numpy/OpenBLAS itself performs in
+// np.linalg.norm).  Reference = zhaozijie2022/dynamic-coverage-control, paths relative to
+// uav_dcc_control/: "CW" envs/mpe/multiagent/CoverageWorld.py, "SC" .../scenarios/coverage.py,
+// "EN" .../environment.py, "WR" envs/wrappers.py.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "dcc_env.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = 64 * kWavesPerBlock;
+constexpr int kTileFloats = 5 * 64;  // one PoI tile of one agent row: 64 PoIs x 5 features
+
+struct KParams {
+    int E, N, M, D, L, H;       // L = N*D floats per env, H = 4 + 2(N-1) header floats per agent row
+    int K;                      // fused steps in this launch
+    int mode;                   // 0 = step, 1 = reset
+    int stageC;                 // floats in the per-wave staging window
+    int vec_ok;                 // obs rows may be stored as float4
+    int use_connect, use_force;
+    int rng;                    // draw actions in-kernel
+    unsigned magicN;            // ceil(2^20 / N): p / N == (p * magicN) >> 20 for p < 4096
+    double r_cover, thr, thr_s, thr2, dmax, contact_force, contact_margin;
+    double dt, keep, max_speed, sens, mass, m_energy;
+    double rew_cover, rew_done, rew_out, bound_soft, bound_hard;
+    float sens_f, mass_f, dt_f, m_energy_f;
+    // state (library owned)
+    const double2* poi;
+    double2* pos;
+    double2* vel;
+    float* energy;
+    uint8_t* done_poi;
+    // inputs
+    const void* actions;        // [K,E,N,2]
+    unsigned long long seed;
+    unsigned step0;
+    int env0, env_total;
+    // outputs (leading K)
+    float* obs;
+    float* reward;
+    uint8_t* done;
+    uint8_t* connect;
+    uint8_t* connect_s;
+    float* coverage;
+    uint8_t* assign;
+    double* reward64;
+};
+
+__device__ __forceinline__ void wave_fence() {
+    // LDS traffic of one wave is issued and serviced in order; this only stops the compiler from
+    // moving LDS accesses across the point where other lanes' data is consumed.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// np.linalg.norm of a 2-vector as numpy evaluates it: x.dot(x) -> OpenBLAS ddot -> fma (see oracle).
+__device__ __forceinline__ double norm2(double a, double b) { return __builtin_sqrt(__builtin_fma(b, b, a * a)); }
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        double w = __shfl_xor(v, o, 64);
+        v = (w < v) ? w : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// numpy's npy_logaddexp(0, y) (CW:136).
+__device__ __forceinline__ double logaddexp0(double y) {
+    if (y == 0.0) return 0.6931471805599453094172321214581766;
+    if (y < 0.0) return log1p(exp(y));
+    return y + log1p(exp(-y));
+}
+
+// Per-wave staging window over the flat [N*D] observation block of one env-step.
+struct Stager {
+    float* stg;    // LDS, 16-byte aligned, C floats
+    float* gout;   // HBM base of this env-step's obs block
+    int C, w0;     // w0 = flat index held by stg[0] (multiple of 4 in vector mode)
+    int vec;
+
+    // Stream out [w0, end) and slide the window so that `s` (next flat index to be produced) fits.
+    __device__ __forceinline__ void flush(int s, int lane) {
+        wave_fence();
+        const int end = vec ? (s & ~3) : s;
+        const int n = end - w0;
+        if (vec) {
+            const int nv = n >> 2;
+            const float4* s4 = reinterpret_cast<const float4*>(stg);
+            float4* g4 = reinterpret_cast<float4*>(gout + w0);
+            int v = lane;
+            for (; v + 192 < nv; v += 256) {
+                float4 x0 = s4[v], x1 = s4[v + 64], x2 = s4[v + 128], x3 = s4[v + 192];
+                g4[v] = x0; g4[v + 64] = x1; g4[v + 128] = x2; g4[v + 192] = x3;
+            }
+            for (; v < nv; v += 64) g4[v] = s4[v];
+        } else {
+            for (int v = lane; v < n; v += 64) gout[w0 + v] = stg[v];
+        }
+        const int tail = s - end;  // 0..3 floats already produced beyond the last full float4
+        float tv = 0.f;
+        if (lane < tail) tv = stg[n + lane];
+        wave_fence();
+        if (lane < tail) stg[lane] = tv;
+        w0 = end;
+        wave_fence();
+    }
+    __device__ __forceinline__ float* reserve(int s, int len, int lane) {
+        if (s + len - w0 > C) flush(s, lane);
+        return stg + (s - w0);
+    }
+};
+
+template <int PPL, bool ACT64>
+__global__ __launch_bounds__(kBlock) void dcc_env_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int env = blockIdx.x * kWavesPerBlock + wid;
+    const int N = p.N, M = p.M, D = p.D, H = p.H;
+
+    // LDS carve: PoI table shared by the block, then per wave: apos[N], avel[N], staging[C].
+    double2* s_poi = reinterpret_cast<double2*>(smem);
+    const int per_wave = N * 32 + p.stageC * 4;
+    unsigned char* wbase = smem + ((M * 16 + 15) & ~15) + wid * per_wave;
+    double2* apos = reinterpret_cast<double2*>(wbase);
+    double2* avel = apos + N;
+    float* stg = reinterpret_cast<float*>(avel + N);
+
+    for (int j = threadIdx.x; j < M; j += kBlock) s_poi[j] = p.poi[j];
+    __syncthreads();
+    if (env >= p.E) return;
+
+    // ---- load state -------------------------------------------------------------------------
+    double px = 0, py = 0, vx = 0, vy = 0;
+    float en[PPL];
+    unsigned dmask = 0;  // bit q: PoI q*64+lane is done
+    double pjx[PPL], pjy[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const int j = q * 64 + lane;
+        en[q] = 0.f;
+        pjx[q] = 0; pjy[q] = 0;
+        if (j < M) { const double2 pj = s_poi[j]; pjx[q] = pj.x; pjy[q] = pj.y; }
+    }
+    if (p.mode == 0) {
+        if (lane < N) {
+            const double2 a = p.pos[(size_t)env * N + lane], b = p.vel[(size_t)env * N + lane];
+            px = a.x; py = a.y; vx = b.x; vy = b.y;
+        }
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            const int j = q * 64 + lane;
+            if (j < M) {
+                en[q] = p.energy[(size_t)env * M + j];
+                if (p.done_poi[(size_t)env * M + j]) dmask |= 1u << q;
+            }
+        }
+    }
+    if (lane < N) { apos[lane] = make_double2(px, py); avel[lane] = make_double2(vx, vy); }
+    wave_fence();
+
+    const unsigned long long fullN = (N >= 64) ? ~0ULL : ((1ULL << N) - 1ULL);
+
+    for (int k = 0; k < p.K; ++k) {
+        const size_t ko = (size_t)k * p.E + env;  // index of this env-step in [K,E] outputs
+        if (p.mode == 0) {
+            // ---- (A) EN:153-201 u = action; u *= 5.0 in the action's dtype ------------------
+            float uxf = 0.f, uyf = 0.f;
+            double uxd = 0, uyd = 0;
+            if (lane < N) {
+                if (p.rng) {
+                    const unsigned long long idx =
+                        ((unsigned long long)(p.step0 + (unsigned)k) * (unsigned long long)p.env_total +
+                         (unsigned long long)(p.env0 + env)) * (unsigned long long)N + (unsigned long long)lane;
+                    const unsigned long long z = splitmix64(p.seed + 0x9E3779B97F4A7C15ULL * (idx + 1ULL));
+                    const unsigned hi = (unsigned)(z >> 40), lo = (unsigned)((z & 0xFFFFFFFFULL) >> 8);
+                    uxf = ((float)hi * (1.0f / 8388608.0f) - 1.0f) * p.sens_f;
+                    uyf = ((float)lo * (1.0f / 8388608.0f) - 1.0f) * p.sens_f;
+                } else if (ACT64) {
+                    const double2 a = reinterpret_cast<const double2*>(p.actions)[ko * N + lane];
+                    uxd = a.x * p.sens; uyd = a.y * p.sens;
+                } else {
+                    const float2 a = reinterpret_cast<const float2*>(p.actions)[ko * N + lane];
+                    uxf = a.x * p.sens_f; uyf = a.y * p.sens_f;
+                }
+            }
+
+            // ---- (B) CW:70-93 update_connect on PRE-move positions --------------------------
+            unsigned long long rowA = 0, rowS = 0;  // lane a: adjacency rows (bit b)
+            bool connect = false, connect_s = false;
+            if (p.use_connect) {
+                const int npairs = N * N;
+                for (int r0 = 0; r0 < npairs; r0 += 64) {
+                    const int pidx = r0 + lane;
+                    const int a = (int)(((unsigned)pidx * p.magicN) >> 20);
+                    const int b = pidx - a * N;
+                    bool adj = false, adjs = false;
+                    if (pidx < npairs && a != b) {
+                        const double2 pa = apos[a], pb = apos[b];
+                        const double d = norm2(pa.x - pb.x, pa.y - pb.y);
+                        adj = d < p.thr;
+                        adjs = adj && (d < p.thr_s);
+                    }
+                    const unsigned long long mA = __ballot(adj), mS = __ballot(adjs);
+                    if (lane < N) {
+                        const int rs = lane * N;  // first pair index of my row
+                        const int lo = rs > r0 ? rs : r0;
+                        const int hi = (rs + N) < (r0 + 64) ? (rs + N) : (r0 + 64);
+                        if (lo < hi) {
+                            const int w = hi - lo;
+                            const unsigned long long msk = (w >= 64) ? ~0ULL : ((1ULL << w) - 1ULL);
+                            rowA |= ((mA >> (lo - r0)) & msk) << (lo - rs);
+                            rowS |= ((mS >> (lo - r0)) & msk) << (lo - rs);
+                        }
+                    }
+                }
+                // connect  = all(sum_k A^k > 0)  <=>  graph(A) connected: BFS from node 0 (A symmetric)
+                unsigned long long visited = 1ULL;
+                for (int it = 1; it < N; ++it) {
+                    const unsigned long long nv = visited | __ballot(lane < N && (rowA & visited) != 0ULL);
+                    if (nv == visited) break;
+                    visited = nv;
+                }
+                connect = (visited == fullN);
+                // connect_ = all(I + sum_{k>=1} A^k A_ > 0) (CW:90 multiplies the just-appended A^k):
+                // N=1 -> True; N=2 -> always False; N>=3 -> connected and every node has an A_ neighbour.
+                const unsigned long long iso = __ballot(lane < N && rowS == 0ULL);
+                connect_s = (N == 1) ? true : (N == 2) ? false : (connect && iso == 0ULL);
+
+                // ---- (D) CW:100-140 connectivity-preserving pull force (wave-uniform branch) ----
+                if (p.use_force && !connect_s) {
+                    double best = 0.0, fx = 0.0, fy = 0.0;
+                    int bi = 0;
+                    const bool branch1 = (iso != 0ULL);
+                    const bool mine = (lane < N) && (branch1 ? (rowS == 0ULL) : true);
+                    if (mine) {
+                        const double2 pa = apos[lane];
+                        for (int b = 0; b < N; ++b) {
+                            const double2 pb = apos[b];
+                            double d = norm2(pa.x - pb.x, pa.y - pb.y);
+                            if (b == lane) d = 1e5;                       // CW:81
+                            else if (!branch1 && d < p.thr2) d = 1e5;     // CW:119-120
+                            if (b == 0 || d < best) { best = d; bi = b; } // np.argmin: first minimum
+                        }
+                    }
+                    unsigned long long todo;
+                    if (branch1) {
+                        todo = iso;  // CW:110-116: every isolated agent, ascending
+                    } else {
+                        // CW:121-123: argmin over the flattened matrix = smallest row minimum, lowest row first
+                        const double g = wave_min_f64(mine ? best : 1.7976931348623157e308);
+                        const unsigned long long eq = __ballot(mine && best == g);
+                        todo = 1ULL << __builtin_ctzll(eq);
+                    }
+                    if (mine && bi != lane && ((todo >> lane) & 1ULL)) {
+                        // CW:129-140 get_connect_force(a = me, b = bi)
+                        const double2 pa = apos[lane], pb = apos[bi];
+                        const double dx = pa.x - pb.x, dy = pa.y - pb.y;
+                        const double dist = norm2(dx, dy);
+                        const double pen = logaddexp0((dist - p.dmax) / p.contact_margin) * p.contact_margin;
+                        fx = p.contact_force * dx / dist * pen;
+                        fy = p.contact_force * dy / dist * pen;
+                    }
+                    // sequential accumulation in the reference's order (float32 round trip per add
+                    // when the action is float32: `p_force[a] += f_a` on a float32 array)
+                    while (todo) {
+                        const int a = __builtin_ctzll(todo);
+                        todo &= todo - 1ULL;
+                        const int b = __builtin_amdgcn_readlane(bi, a);
+                        const double fax = readlane_f64(fx, a), fay = readlane_f64(fy, a);
+                        if (a == b) continue;  // get_connect_force returns [0, 0] (CW:130-131)
+                        if (lane == a) {
+                            if (ACT64) { uxd += -fax; uyd += -fay; }
+                            else { uxf = (float)((double)uxf + (-fax)); uyf = (float)((double)uyf + (-fay)); }
+                        }
+                        if (lane == b) {
+                            if (ACT64) { uxd += fax; uyd += fay; }
+                            else { uxf = (float)((double)uxf + fax); uyf = (float)((double)uyf + fay); }
+                        }
+                    }
+                }
+            }
+
+            // ---- (E) CW:142-155 integrate_state ----------------------------------------------
+            if (lane < N) {
+                vx = vx * p.keep; vy = vy * p.keep;
+                if (ACT64) {
+                    vx += (uxd / p.mass) * p.dt; vy += (uyd / p.mass) * p.dt;
+                } else {
+                    const float ax = (uxf / p.mass_f) * p.dt_f, ay = (uyf / p.mass_f) * p.dt_f;
+                    vx += (double)ax; vy += (double)ay;
+                }
+                const double speed = __builtin_sqrt(vx * vx + vy * vy);
+                if (speed > p.max_speed) { vx = vx / speed * p.max_speed; vy = vy / speed * p.max_speed; }
+                px += vx * p.dt; py += vy * p.dt;
+                apos[lane] = make_double2(px, py);
+                avel[lane] = make_double2(vx, vy);
+            }
+            wave_fence();
+
+            // ---- (F) CW:157-174 update_energy + SC:80-97 reward terms on POST-move positions ---
+            int n_done = 0, n_just = 0;
+            double part = 0.0;  // per-lane share of (OOB terms - sum of min distances)
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                const int j = q * 64 + lane;
+                const bool valid = j < M;
+                int cnt = 0, amin = 0;
+                double dmin = 0.0;
+                for (int i = 0; i < N; ++i) {
+                    const double2 xa = apos[i];
+                    const double d = norm2(pjx[q] - xa.x, pjy[q] - xa.y);
+                    cnt += (d <= p.r_cover) ? 1 : 0;
+                    if (i == 0 || d < dmin) { dmin = d; amin = i; }
+                }
+                bool dn = (dmask >> q) & 1u, just = false;
+                if (valid && !dn) {
+                    en[q] += (float)cnt;
+                    if (en[q] >= p.m_energy_f) { dn = true; just = true; dmask |= 1u << q; }
+                }
+                n_done += __popcll(__ballot(valid && dn));
+                n_just += __popcll(__ballot(just));
+                if (valid && !dn) part -= dmin;
+                if (valid && p.assign) p.assign[ko * M + j] = (uint8_t)amin;
+            }
+            bool oob = false;
+            if (lane < N) {
+                const double ax = fabs(px), ay = fabs(py);
+                double s = 0.0;
+                if (ax > p.bound_soft) s += ax - p.bound_soft;
+                if (ay > p.bound_soft) s += ay - p.bound_soft;
+                part += s * p.rew_out;
+                oob = (ax > p.bound_hard) || (ay > p.bound_hard);
+                if (oob) part += p.rew_out;
+            }
+            const bool any_oob = __ballot(oob) != 0ULL;
+            const bool all_done = (n_done == M);
+            double base = wave_sum_f64(part);
+            if (all_done) base += p.rew_done;
+            // EN:106-108 sum over the N per-agent rewards; `just` bonus is paid once (SC:87-89)
+            const double R = (double)N * base + p.rew_cover * (double)n_just;
+            const bool env_done = all_done || any_oob;  // SC:112-117
+            if (lane == 0) {
+                if (p.reward) p.reward[ko] = (float)R;
+                if (p.reward64) p.reward64[ko] = R;
+                if (p.done) p.done[ko] = env_done ? 1 : 0;
+                if (p.connect) p.connect[ko] = connect ? 1 : 0;
+                if (p.connect_s) p.connect_s[ko] = connect_s ? 1 : 0;
+                if (p.coverage) p.coverage[ko] = (float)((double)n_done / (double)M);
+            }
+            // ---- (I) WR:104-109 auto-reset -> SC:64-78 -----------------------------------------
+            if (env_done) {
+                px = py = vx = vy = 0.0;
+                dmask = 0;
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) en[q] = 0.f;
+                if (lane < N) { apos[lane] = make_double2(0.0, 0.0); avel[lane] = make_double2(0.0, 0.0); }
+                wave_fence();
+            }
+        }
+
+        // ---- (G) SC:99-110 observation rows, streamed through the LDS staging window ----------
+        if (p.obs) {
+            Stager st;
+            st.stg = stg; st.C = p.stageC; st.w0 = 0; st.vec = p.vec_ok;
+            st.gout = p.obs + ko * (size_t)p.L;
+            for (int i = 0; i < N; ++i) {
+                const double2 xi = apos[i];
+                // header: vel(2) pos(2) (x_k - x_i for k != i)
+                for (int f0 = 0; f0 < H; f0 += 64) {
+                    const int len = (H - f0) < 64 ? (H - f0) : 64;
+                    float* dst = st.reserve(i * D + f0, len, lane);
+                    const int f = f0 + lane;
+                    if (f < H) {
+                        double v;
+                        if (f < 2) { const double2 w = avel[i]; v = f ? w.y : w.x; }
+                        else if (f < 4) { v = (f == 3) ? xi.y : xi.x; }
+                        else {
+                            const int kk = (f - 4) >> 1, c = (f - 4) & 1;
+                            const double2 xo = apos[kk + (kk >= i ? 1 : 0)];
+                            v = c ? (xo.y - xi.y) : (xo.x - xi.x);
+                        }
+                        dst[lane] = (float)v;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) {
+                    if (q * 64 < M) {
+                        const int cntj = (M - q * 64) < 64 ? (M - q * 64) : 64;
+                        float* dst = st.reserve(i * D + H + q * kTileFloats, 5 * cntj, lane);
+                        if (lane < cntj) {
+                            float* d5 = dst + 5 * lane;
+                            d5[0] = (float)(pjx[q] - xi.x);
+                            d5[1] = (float)(pjy[q] - xi.y);
+                            d5[2] = en[q];
+                            d5[3] = p.m_energy_f;
+                            d5[4] = ((dmask >> q) & 1u) ? 1.f : 0.f;
+                        }
+                    }
+                }
+            }
+            st.flush(p.L, lane);
+        }
+    }
+
+    // ---- store state ------------------------------------------------------------------------------
+    if (lane < N) {
+        p.pos[(size_t)env * N + lane] = make_double2(px, py);
+        p.vel[(size_t)env * N + lane] = make_double2(vx, vy);
+    }
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const int j = q * 64 + lane;
+        if (j < M) {
+            p.energy[(size_t)env * M + j] = en[q];
+            p.done_poi[(size_t)env * M + j] = (dmask >> q) & 1u;
+        }
+    }
+}
+
+// ================================ host side =====================================================
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(DCC_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+    } while (0)
+
+}  // namespace
+
+struct dcc_env {
+    dcc_env_cfg cfg;
+    int device;
+    int D, L, PPL;
+    KParams base;
+    double2* d_poi = nullptr;
+    double2* d_pos = nullptr;
+    double2* d_vel = nullptr;
+    float* d_energy = nullptr;
+    uint8_t* d_done = nullptr;
+    size_t lds_bytes = 0;
+};
+
+namespace {
+
+typedef void (*kernel_fn)(const KParams);
+
+template <bool ACT64>
+kernel_fn pick_kernel(int ppl) {
+    switch (ppl) {
+        case 1: return dcc_env_kernel<1, ACT64>;
+        case 2: return dcc_env_kernel<2, ACT64>;
+        case 4: return dcc_env_kernel<4, ACT64>;
+        case 8: return dcc_env_kernel<8, ACT64>;
+        default: return dcc_env_kernel<16, ACT64>;
+    }
+}
+
+int launch(dcc_env* env, KParams& p, bool act64, void* stream) {
+    kernel_fn fn = act64 ? pick_kernel<true>(env->PPL) : pick_kernel<false>(env->PPL);
+    const int grid = (p.E + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (env->lds_bytes > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)env->lds_bytes));
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), env->lds_bytes, s, p);
+    HIP_TRY(hipGetLastError());
+    return DCC_OK;
+}
+
+int fill_out(KParams& p, const dcc_env_out* out) {
+    p.obs = out ? out->obs : nullptr;
+    p.reward = out ? out->reward : nullptr;
+    p.done = out ? out->done : nullptr;
+    p.connect = out ? out->connect : nullptr;
+    p.connect_s = out ? out->connect_s : nullptr;
+    p.coverage = out ? out->coverage : nullptr;
+    p.assign = out ? out->assign : nullptr;
+    p.reward64 = out ? out->reward64 : nullptr;
+    p.vec_ok = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 15u) == 0);
+    return DCC_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+        target = dev;
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != target) (void)hipSetDevice(prev); }
+    int target = -1;
+};
+
+}  // namespace
+
+extern "C" {
+
+int dcc_abi_version(void) { return DCC_ABI_VERSION; }
+const char* dcc_last_error(void) { return g_err.c_str(); }
+
+void dcc_env_cfg_default(dcc_env_cfg* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->device = -1;
+    c->r_cover = 0.25; c->r_comm = 0.5;          // SC:20 defaults (dcc.yaml overrides: 0.2 / 0.4)
+    c->comm_r_scale = 0.9; c->comm_force_scale = 0.0;  // CW:7
+    c->dt = 0.1; c->damping = 0.25; c->max_speed = 0.5; c->sensitivity = 5.0; c->mass = 1.0;
+    c->contact_margin = 1e-3; c->m_energy = 5.0;
+    c->rew_cover = 75.0; c->rew_done = 1500.0; c->rew_out = -100.0;
+    c->bound_soft = 1.0; c->bound_hard = 1.5;
+}
+
+int64_t dcc_env_bytes_per_step(int32_t N, int32_t M, int32_t with_actions, int32_t with_obs) {
+    const int64_t D = 4 + 2 * (int64_t)(N - 1) + 5 * (int64_t)M;
+    int64_t b = 40 * (int64_t)N + 11 * (int64_t)M + 11;
+    if (!with_actions) b -= 8 * (int64_t)N;
+    if (with_obs) b += 4 * (int64_t)N * D;
+    return b;
+}
+
+int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
+    if (!c || !out) return fail(DCC_EINVAL, "dcc_env_create: null argument");
+    *out = nullptr;
+    if (c->n_envs < 1) return fail(DCC_EINVAL, "dcc_env_create: n_envs must be >= 1");
+    if (c->n_agents < 1 || c->n_agents > DCC_MAX_AGENTS)
+        return fail(DCC_EINVAL, "dcc_env_create: n_agents must be in 1..64 (one UAV per wavefront lane)");
+    if (c->n_pois < 1 || c->n_pois > DCC_MAX_POIS) return fail(DCC_EINVAL, "dcc_env_create: n_pois must be in 1..1024");
+    if (!c->poi_xy) return fail(DCC_EINVAL, "dcc_env_create: poi_xy is NULL");
+    if (!(c->mass > 0) || !(c->dt > 0) || !(c->r_cover >= 0) || !(c->r_comm >= 0) || !(c->contact_margin > 0))
+        return fail(DCC_EINVAL, "dcc_env_create: non-positive mass/dt/contact_margin or negative radius");
+    if (c->comm_force_scale > 0 && !(c->comm_r_scale > 0))
+        return fail(DCC_EINVAL, "dcc_env_create: comm_force_scale > 0 requires comm_r_scale > 0");
+    if (c->comm_force_scale < 0) return fail(DCC_EINVAL, "dcc_env_create: comm_force_scale < 0");
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(DCC_EHIP, "dcc_env_create: no HIP device visible (this library has no CPU path)");
+    int dev = c->device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(DCC_EINVAL, "dcc_env_create: device ordinal out of range");
+    DeviceGuard guard(dev);
+    if (!guard.ok) return fail(DCC_EHIP, "dcc_env_create: hipSetDevice failed");
+
+    dcc_env* e = new (std::nothrow) dcc_env();
+    if (!e) return fail(DCC_ENOMEM, "dcc_env_create: out of host memory");
+    e->cfg = *c;
+    e->cfg.poi_xy = nullptr;
+    e->device = dev;
+    const int E = c->n_envs, N = c->n_agents, M = c->n_pois;
+    e->D = 4 + 2 * (N - 1) + 5 * M;
+    e->L = N * e->D;
+    int ppl = (M + 63) / 64, p2 = 1;
+    while (p2 < ppl) p2 <<= 1;
+    e->PPL = p2;
+
+    KParams& p = e->base;
+    std::memset(&p, 0, sizeof(p));
+    p.E = E; p.N = N; p.M = M; p.D = e->D; p.L = e->L; p.H = 4 + 2 * (N - 1);
+    p.K = 1; p.mode = 0;
+    p.stageC = 2048;
+    p.use_connect = c->comm_r_scale > 0;
+    const double contact_force = 1e+2 * c->comm_force_scale;  // core.py:109 scaled at CW:16
+    p.use_force = contact_force > 0;
+    p.magicN = ((1u << 20) + (unsigned)N - 1u) / (unsigned)N;
+    p.r_cover = c->r_cover;
+    p.thr = c->r_comm + c->r_comm;                          // CW:77
+    p.thr_s = c->comm_r_scale * (c->r_comm + c->r_comm);    // CW:79
+    p.thr2 = c->comm_r_scale * 2 * c->r_comm;               // CW:119 (its own rounding order)
+    p.dmax = (c->r_comm + c->r_comm) * c->comm_r_scale;     // CW:134
+    p.contact_force = contact_force; p.contact_margin = c->contact_margin;
+    p.dt = c->dt; p.keep = 1 - c->damping; p.max_speed = c->max_speed; p.sens = c->sensitivity; p.mass = c->mass;
+    p.m_energy = c->m_energy;
+    p.rew_cover = c->rew_cover; p.rew_done = c->rew_done; p.rew_out = c->rew_out;
+    p.bound_soft = c->bound_soft; p.bound_hard = c->bound_hard;
+    p.sens_f = (float)c->sensitivity; p.mass_f = (float)c->mass; p.dt_f = (float)c->dt; p.m_energy_f = (float)c->m_energy;
+    p.env0 = 0; p.env_total = E;
+
+    e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)p.stageC * 4);
+
+    auto cleanup = [&](int code, const std::string& m) { dcc_env_destroy(e); return fail(code, m); };
+    hipError_t err;
+    if ((err = hipMalloc(&e->d_poi, sizeof(double2) * M)) != hipSuccess ||
+        (err = hipMalloc(&e->d_pos, sizeof(double2) * (size_t)E * N)) != hipSuccess ||
+        (err = hipMalloc(&e->d_vel, sizeof(double2) * (size_t)E * N)) != hipSuccess ||
+        (err = hipMalloc(&e->d_energy, sizeof(float) * (size_t)E * M)) != hipSuccess ||
+        (err = hipMalloc(&e->d_done, (size_t)E * M)) != hipSuccess)
+        return cleanup(DCC_ENOMEM, std::string("dcc_env_create: hipMalloc: ") + hipGetErrorString(err));
+    if ((err = hipMemcpy(e->d_poi, c->poi_xy, sizeof(double2) * M, hipMemcpyHostToDevice)) != hipSuccess ||
+        (err = hipMemset(e->d_pos, 0, sizeof(double2) * (size_t)E * N)) != hipSuccess ||
+        (err = hipMemset(e->d_vel, 0, sizeof(double2) * (size_t)E * N)) != hipSuccess ||
+        (err = hipMemset(e->d_energy, 0, sizeof(float) * (size_t)E * M)) != hipSuccess ||
+        (err = hipMemset(e->d_done, 0, (size_t)E * M)) != hipSuccess)
+        return cleanup(DCC_EHIP, std::string("dcc_env_create: init copy: ") + hipGetErrorString(err));
+    p.poi = e->d_poi; p.pos = e->d_pos; p.vel = e->d_vel; p.energy = e->d_energy; p.done_poi = e->d_done;
+    *out = e;
+    return DCC_OK;
+}
+
+int dcc_env_destroy(dcc_env* e) {
+    if (!e) return DCC_OK;
+    {
+        DeviceGuard guard(e->device);
+        (void)hipFree(e->d_poi); (void)hipFree(e->d_pos); (void)hipFree(e->d_vel);
+        (void)hipFree(e->d_energy); (void)hipFree(e->d_done);
+    }
+    delete e;
+    return DCC_OK;
+}
+
+int dcc_env_obs_dim(const dcc_env* e) { return e ? e->D : DCC_EINVAL; }
+
+int dcc_env_reset(dcc_env* e, float* obs, void* stream) {
+    if (!e) return fail(DCC_EINVAL, "dcc_env_reset: null env");
+    DeviceGuard guard(e->device);
+    KParams p = e->base;
+    p.mode = 1; p.K = 1;
+    dcc_env_out o;
+    std::memset(&o, 0, sizeof(o));
+    o.obs = obs;
+    fill_out(p, &o);
+    return launch(e, p, false, stream);
+}
+
+int dcc_env_step(dcc_env* e, const void* actions, int act_dtype, const dcc_env_out* out, void* stream) {
+    if (!e) return fail(DCC_EINVAL, "dcc_env_step: null env");
+    if (!actions) return fail(DCC_EINVAL, "dcc_env_step: actions is NULL");
+    if (act_dtype != DCC_ACT_F32 && act_dtype != DCC_ACT_F64) return fail(DCC_EINVAL, "dcc_env_step: bad act_dtype");
+    const uintptr_t align = act_dtype == DCC_ACT_F64 ? 15u : 7u;
+    if (reinterpret_cast<uintptr_t>(actions) & align) return fail(DCC_EINVAL, "dcc_env_step: actions pointer misaligned");
+    DeviceGuard guard(e->device);
+    KParams p = e->base;
+    p.mode = 0; p.K = 1; p.rng = 0; p.actions = actions;
+    fill_out(p, out);
+    return launch(e, p, act_dtype == DCC_ACT_F64, stream);
+}
+
+int dcc_env_rollout(dcc_env* e, int32_t K, const float* actions, uint64_t seed, uint32_t step0, int32_t env0,
+                    int32_t env_total, const dcc_env_out* out, void* stream) {
+    if (!e) return fail(DCC_EINVAL, "dcc_env_rollout: null env");
+    if (K < 1) return fail(DCC_EINVAL, "dcc_env_rollout: K must be >= 1");
+    if (actions && (reinterpret_cast<uintptr_t>(actions) & 7u)) return fail(DCC_EINVAL, "dcc_env_rollout: actions misaligned");
+    if (!actions && (env0 < 0 || env_total < env0 + e->cfg.n_envs))
+        return fail(DCC_EINVAL, "dcc_env_rollout: env0/env_total do not cover this shard");
+    DeviceGuard guard(e->device);
+    KParams p = e->base;
+    p.mode = 0; p.K = K; p.rng = actions ? 0 : 1; p.actions = actions;
+    p.seed = seed; p.step0 = step0; p.env0 = env0; p.env_total = env_total;
+    fill_out(p, out);
+    return launch(e, p, false, stream);
+}
+
+int dcc_env_get_state(dcc_env* e, double* pos, double* vel, float* energy, uint8_t* done, void* stream) {
+    if (!e) return fail(DCC_EINVAL, "dcc_env_get_state: null env");
+    DeviceGuard guard(e->device);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t E = e->cfg.n_envs, N = e->cfg.n_agents, M = e->cfg.n_pois;
+    if (pos) HIP_TRY(hipMemcpyAsync(pos, e->d_pos, sizeof(double2) * E * N, hipMemcpyDeviceToDevice, s));
+    if (vel) HIP_TRY(hipMemcpyAsync(vel, e->d_vel, sizeof(double2) * E * N, hipMemcpyDeviceToDevice, s));
+    if (energy) HIP_TRY(hipMemcpyAsync(energy, e->d_energy, sizeof(float) * E * M, hipMemcpyDeviceToDevice, s));
+    if (done) HIP_TRY(hipMemcpyAsync(done, e->d_done, E * M, hipMemcpyDeviceToDevice, s));
+    return DCC_OK;
+}
+
+int dcc_env_set_state(dcc_env* e, const double* pos, const double* vel, const float* energy, const uint8_t* done,
+                      void* stream) {
+    if (!e) return fail(DCC_EINVAL, "dcc_env_set_state: null env");
+    DeviceGuard guard(e->device);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t E = e->cfg.n_envs, N = e->cfg.n_agents, M = e->cfg.n_pois;
+    if (pos) HIP_TRY(hipMemcpyAsync(e->d_pos, pos, sizeof(double2) * E * N, hipMemcpyDeviceToDevice, s));
+    if (vel) HIP_TRY(hipMemcpyAsync(e->d_vel, vel, sizeof(double2) * E * N, hipMemcpyDeviceToDevice, s));
+    if (energy) HIP_TRY(hipMemcpyAsync(e->d_energy, energy, sizeof(float) * E * M, hipMemcpyDeviceToDevice, s));
+    if (done) HIP_TRY(hipMemcpyAsync(e->d_done, done, E * M, hipMemcpyDeviceToDevice, s));
+    return DCC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,231 @@
+"""ctypes binding of libdcc_hip.so (include/dcc_env.h) -- the thin C-ABI seam between the Python
+host code and the hand-written HIP kernels.
+
+There is NO CPU fallback: if the shared library is missing or no HIP device is visible, loading /
+creating raises.  Tensors are torch CUDA(=HIP) tensors; only their data_ptr() crosses the ABI.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch  # imported before the library so that both share one HIP runtime (libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("DCC_HIP_LIB", os.path.join(_HERE, "csrc", "libdcc_hip.so"))
+
+ACT_F32, ACT_F64 = 0, 1
+_vp = ctypes.c_void_p
+
+
+class DccError(RuntimeError):
+    pass
+
+
+class EnvCfg(ctypes.Structure):
+    _fields_ = [("n_envs", ctypes.c_int32), ("n_agents", ctypes.c_int32), ("n_pois", ctypes.c_int32),
+                ("device", ctypes.c_int32),
+                ("r_cover", ctypes.c_double), ("r_comm", ctypes.c_double), ("comm_r_scale", ctypes.c_double),
+                ("comm_force_scale", ctypes.c_double),
+                ("dt", ctypes.c_double), ("damping", ctypes.c_double), ("max_speed", ctypes.c_double),
+                ("sensitivity", ctypes.c_double), ("mass", ctypes.c_double),
+                ("contact_margin", ctypes.c_double), ("m_energy", ctypes.c_double),
+                ("rew_cover", ctypes.c_double), ("rew_done", ctypes.c_double), ("rew_out", ctypes.c_double),
+                ("bound_soft", ctypes.c_double), ("bound_hard", ctypes.c_double),
+                ("poi_xy", _vp)]
+
+
+class EnvOut(ctypes.Structure):
+    _fields_ = [("obs", _vp), ("reward", _vp), ("done", _vp), ("connect", _vp), ("connect_s", _vp),
+                ("coverage", _vp), ("assign", _vp), ("reward64", _vp)]
+
+
+EXPORTS = ["dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
+           "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout", "dcc_env_get_state",
+           "dcc_env_set_state", "dcc_env_bytes_per_step"]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libdcc_hip.so and declare every prototype of include/dcc_env.h.  Raises if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise DccError("HIP extension %s not found: build it with `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    L = ctypes.CDLL(path)
+    L.dcc_abi_version.restype = ctypes.c_int
+    L.dcc_last_error.restype = ctypes.c_char_p
+    L.dcc_env_cfg_default.argtypes = [ctypes.POINTER(EnvCfg)]
+    L.dcc_env_cfg_default.restype = None
+    L.dcc_env_create.argtypes = [ctypes.POINTER(EnvCfg), ctypes.POINTER(_vp)]
+    L.dcc_env_destroy.argtypes = [_vp]
+    L.dcc_env_obs_dim.argtypes = [_vp]
+    L.dcc_env_reset.argtypes = [_vp, _vp, _vp]
+    L.dcc_env_step.argtypes = [_vp, _vp, ctypes.c_int, ctypes.POINTER(EnvOut), _vp]
+    L.dcc_env_rollout.argtypes = [_vp, ctypes.c_int32, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32,
+                                  ctypes.c_int32, ctypes.POINTER(EnvOut), _vp]
+    L.dcc_env_get_state.argtypes = [_vp] * 6
+    L.dcc_env_set_state.argtypes = [_vp] * 6
+    L.dcc_env_bytes_per_step.argtypes = [ctypes.c_int32] * 4
+    L.dcc_env_bytes_per_step.restype = ctypes.c_int64
+    if L.dcc_abi_version() != 1:
+        raise DccError("libdcc_hip.so ABI version %d != 1" % L.dcc_abi_version())
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise DccError("%s failed (%d): %s" % (what, rc, load_library().dcc_last_error().decode()))
+
+
+def _ptr(t):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def bytes_per_step(n_agents, n_pois, with_actions=True, with_obs=True):
+    return int(load_library().dcc_env_bytes_per_step(n_agents, n_pois, int(with_actions), int(with_obs)))
+
+
+class HipCoverageEnv:
+    """Low-level handle: E batched envs resident on one GPU; all I/O are torch device tensors."""
+
+    def __init__(self, n_envs, n_agents, n_pois, poi_xy, r_cover=0.2, r_comm=0.4, comm_r_scale=0.95,
+                 comm_force_scale=0.0, device=None, **consts):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise DccError("no HIP device visible: the coverage env has no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        poi = np.ascontiguousarray(poi_xy, np.float64)
+        if poi.shape != (n_pois, 2):
+            raise ValueError("poi_xy must be [n_pois, 2]")
+        cfg = EnvCfg()
+        self.lib.dcc_env_cfg_default(ctypes.byref(cfg))
+        cfg.n_envs, cfg.n_agents, cfg.n_pois, cfg.device = n_envs, n_agents, n_pois, self.device.index
+        cfg.r_cover, cfg.r_comm, cfg.comm_r_scale, cfg.comm_force_scale = r_cover, r_comm, comm_r_scale, comm_force_scale
+        for k, v in consts.items():
+            if not hasattr(cfg, k):
+                raise TypeError("unknown env constant %r" % k)
+            setattr(cfg, k, v)
+        cfg.poi_xy = poi.ctypes.data_as(_vp)
+        h = _vp()
+        _check(self.lib.dcc_env_create(ctypes.byref(cfg), ctypes.byref(h)), "dcc_env_create")
+        self._h = h
+        self.E, self.N, self.M = n_envs, n_agents, n_pois
+        self.D = self.lib.dcc_env_obs_dim(h)
+        self.poi = poi
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.dcc_env_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- allocation helpers ---------------------------------------------------------------------
+    def alloc_out(self, K=None, obs=True, assign=True, reward64=False):
+        lead = () if K is None else (K,)
+        mk = lambda shape, dt: torch.empty(lead + shape, dtype=dt, device=self.device)
+        out = dict(reward=mk((self.E,), torch.float32), done=mk((self.E,), torch.uint8),
+                   connect=mk((self.E,), torch.uint8), connect_s=mk((self.E,), torch.uint8),
+                   coverage=mk((self.E,), torch.float32))
+        if obs:
+            out["obs"] = mk((self.E, self.N, self.D), torch.float32)
+        if assign:
+            out["assign"] = mk((self.E, self.M), torch.uint8)
+        if reward64:
+            out["reward64"] = mk((self.E,), torch.float64)
+        return out
+
+    def _out_struct(self, out, K=None):
+        o = EnvOut()
+        lead = () if K is None else (K,)
+        shapes = dict(obs=(self.E, self.N, self.D), reward=(self.E,), done=(self.E,), connect=(self.E,),
+                      connect_s=(self.E,), coverage=(self.E,), assign=(self.E, self.M), reward64=(self.E,))
+        dts = dict(obs=torch.float32, reward=torch.float32, done=torch.uint8, connect=torch.uint8,
+                   connect_s=torch.uint8, coverage=torch.float32, assign=torch.uint8, reward64=torch.float64)
+        for k, t in out.items():
+            if t is None:
+                continue
+            if k not in shapes:
+                raise KeyError(k)
+            if tuple(t.shape) != lead + shapes[k] or t.dtype != dts[k] or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("output %r must be contiguous %s %s on %s" % (k, lead + shapes[k], dts[k], self.device))
+            setattr(o, k, t.data_ptr())
+        return o
+
+    # ---- entry points -----------------------------------------------------------------------------
+    def reset(self, obs=None):
+        if obs is None:
+            obs = torch.empty((self.E, self.N, self.D), dtype=torch.float32, device=self.device)
+        self._out_struct(dict(obs=obs))
+        with torch.cuda.device(self.device):
+            _check(self.lib.dcc_env_reset(self._h, _ptr(obs), _stream()), "dcc_env_reset")
+        return obs
+
+    def step(self, actions, out=None):
+        if actions.device != self.device or not actions.is_contiguous() or tuple(actions.shape) != (self.E, self.N, 2):
+            raise ValueError("actions must be a contiguous [E,N,2] tensor on %s" % self.device)
+        if actions.dtype == torch.float32:
+            dt = ACT_F32
+        elif actions.dtype == torch.float64:
+            dt = ACT_F64
+        else:
+            raise ValueError("actions must be float32 or float64")
+        if out is None:
+            out = self.alloc_out()
+        o = self._out_struct(out)
+        with torch.cuda.device(self.device):
+            _check(self.lib.dcc_env_step(self._h, _ptr(actions), dt, ctypes.byref(o), _stream()), "dcc_env_step")
+        return out
+
+    def rollout(self, K, actions=None, seed=0, step0=0, env0=0, env_total=None, out=None):
+        if actions is not None:
+            if (actions.device != self.device or actions.dtype != torch.float32 or not actions.is_contiguous()
+                    or tuple(actions.shape) != (K, self.E, self.N, 2)):
+                raise ValueError("actions must be a contiguous float32 [K,E,N,2] tensor on %s" % self.device)
+        if out is None:
+            out = self.alloc_out(K)
+        o = self._out_struct(out, K)
+        with torch.cuda.device(self.device):
+            _check(self.lib.dcc_env_rollout(self._h, K, _ptr(actions), seed, step0, env0,
+                                            self.E if env_total is None else env_total, ctypes.byref(o), _stream()),
+                   "dcc_env_rollout")
+        return out
+
+    def get_state(self):
+        d = self.device
+        st = dict(pos=torch.empty((self.E, self.N, 2), dtype=torch.float64, device=d),
+                  vel=torch.empty((self.E, self.N, 2), dtype=torch.float64, device=d),
+                  energy=torch.empty((self.E, self.M), dtype=torch.float32, device=d),
+                  done=torch.empty((self.E, self.M), dtype=torch.uint8, device=d))
+        with torch.cuda.device(self.device):
+            _check(self.lib.dcc_env_get_state(self._h, _ptr(st["pos"]), _ptr(st["vel"]), _ptr(st["energy"]),
+                                              _ptr(st["done"]), _stream()), "dcc_env_get_state")
+        return st
+
+    def set_state(self, pos=None, vel=None, energy=None, done=None):
+        def c(t, dt, shape):
+            if t is None:
+                return None
+            t = torch.as_tensor(t).to(device=self.device, dtype=dt).contiguous()
+            if tuple(t.shape) != shape:
+                raise ValueError("bad state shape %s, want %s" % (tuple(t.shape), shape))
+            return t
+        pos = c(pos, torch.float64, (self.E, self.N, 2)); vel = c(vel, torch.float64, (self.E, self.N, 2))
+        energy = c(energy, torch.float32, (self.E, self.M)); done = c(done, torch.uint8, (self.E, self.M))
+        with torch.cuda.device(self.device):
+            _check(self.lib.dcc_env_set_state(self._h, _ptr(pos), _ptr(vel), _ptr(energy), _ptr(done), _stream()),
+                   "dcc_env_set_state")
+            torch.cuda.current_stream().synchronize()  # inputs may be temporaries

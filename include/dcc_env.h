@@ -1,0 +1,133 @@
+/*
+ * dcc_env.h -- C-ABI of libdcc_hip.so: the batched multi-agent coverage environment on MI355X.
+ *
+ * The reference (zhaozijie2022/dynamic-coverage-control) is pure Python and has no FFI; its only
+ * extension seam is duck typing: `make_env(cfg)` (uav_dcc_control/envs/make_env.py:15-49) returns a
+ * vec-env with reset()/step() (uav_dcc_control/envs/wrappers.py:133-261).  This header is the
+ * boundary a ctypes binding of that seam calls; INTEGRATION.md shows the binding.
+ * Paths below are relative to uav_dcc_control/ in the reference.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative DCC_E* code; dcc_last_error() gives the
+ *     message of the last failure on the calling thread.  No exceptions / Python objects cross.
+ *   - all I/O buffers are DEVICE pointers owned by the caller (e.g. torch tensors' data_ptr());
+ *     the library owns only its internal env state (pos, vel, energy, done) and the PoI table.
+ *   - calls are asynchronous and ordered on the hipStream_t passed as `stream` (void*; NULL = the
+ *     default stream).  No hidden device synchronisation.  A handle is not thread-safe.
+ *   - plain C types only; no torch types.
+ */
+#ifndef DCC_ENV_H
+#define DCC_ENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define DCC_API __attribute__((visibility("default")))
+#else
+#define DCC_API
+#endif
+
+#define DCC_ABI_VERSION 1
+
+#define DCC_OK 0
+#define DCC_EINVAL (-1)   /* bad argument / shape */
+#define DCC_EHIP (-2)     /* HIP runtime error (message in dcc_last_error) */
+#define DCC_ENOMEM (-3)
+#define DCC_EUNSUPPORTED (-4)
+
+#define DCC_MAX_AGENTS 64   /* one UAV per lane of a wavefront */
+#define DCC_MAX_POIS 1024   /* <= 16 PoIs per lane */
+
+/* action dtypes accepted by step/rollout: the reference keeps the caller's dtype through
+ * `u *= 5.0` and the force accumulation (envs/mpe/multiagent/environment.py:186-190,
+ * CoverageWorld.py:115-116,147); float32 is what Learner.collect passes (learner.py:240-250). */
+#define DCC_ACT_F32 0
+#define DCC_ACT_F64 1
+
+/* Scenario + world constants.  Defaults of the reference are given by dcc_env_cfg_default():
+ * envs/mpe/multiagent/scenarios/coverage.py:20-31 (r_cover, r_comm, m_energy, rew_*),
+ * core.py:105-110 (dt, damping, contact_force, contact_margin), coverage.py:54 (max_speed),
+ * environment.py:186 (sensitivity), CoverageWorld.py:7-23 (comm_r_scale, comm_force_scale, dt). */
+typedef struct dcc_env_cfg {
+    int32_t n_envs;            /* E: independent env instances on this device */
+    int32_t n_agents;          /* N: UAVs per env, 1..DCC_MAX_AGENTS */
+    int32_t n_pois;            /* M: PoIs per env, 1..DCC_MAX_POIS */
+    int32_t device;            /* HIP device ordinal, -1 = current device */
+    double r_cover;            /* coverage radius (<=) */
+    double r_comm;             /* communication radius; adjacency iff d < r_a + r_b */
+    double comm_r_scale;       /* >0: connectivity flags computed; radius scale for the pull force */
+    double comm_force_scale;   /* contact_force = 1e2 * comm_force_scale; 0 disables the force */
+    double dt, damping, max_speed, sensitivity, mass;
+    double contact_margin, m_energy;
+    double rew_cover, rew_done, rew_out;
+    double bound_soft, bound_hard;   /* 1.0 (penalty) and 1.5 (done) in coverage.py:93-96,112-116 */
+    const double* poi_xy;      /* HOST pointer, [M,2] float64 (pos_pois.npy rows); copied */
+} dcc_env_cfg;
+
+typedef struct dcc_env dcc_env;   /* opaque */
+
+/* Per-step outputs.  Any pointer may be NULL (that output is skipped).  With dcc_env_rollout
+ * every array has a leading K (step) dimension. */
+typedef struct dcc_env_out {
+    float*   obs;        /* [E,N,D] float32: what the vec-env returns (reset obs for envs that just
+                            finished, wrappers.py:104-109), cast as SharedReplayBuffer stores it */
+    float*   reward;     /* [E]  shared reward every agent of the env receives (environment.py:106-108) */
+    uint8_t* done;       /* [E]  np.all(done_n) (coverage.py:112-117); terminal-step value */
+    uint8_t* connect;    /* [E]  world.connect  (CoverageWorld.py:92), from PRE-move positions */
+    uint8_t* connect_s;  /* [E]  world.connect_ (CoverageWorld.py:93) */
+    float*   coverage;   /* [E]  info["coverage_rate"] (mpe/uav_dcc.py:48) */
+    uint8_t* assign;     /* [E,M] PoI-assignment index argmin_i ||x_i - p_j|| (first min), terminal positions */
+    double*  reward64;   /* [E]  the same reward before the float32 cast (optional) */
+} dcc_env_out;
+
+DCC_API int         dcc_abi_version(void);
+DCC_API const char* dcc_last_error(void);
+
+/* Fill cfg with the reference's constants (n_envs/n_agents/n_pois/poi_xy left 0/NULL). */
+DCC_API void dcc_env_cfg_default(dcc_env_cfg* cfg);
+
+/* Replaces: make_env + DCEnv.__init__ + Scenario.make_world/reset_world
+ * (envs/make_env.py:15-49, envs/mpe/uav_dcc.py:8-44, scenarios/coverage.py:33-78). */
+DCC_API int dcc_env_create(const dcc_env_cfg* cfg, dcc_env** out);
+DCC_API int dcc_env_destroy(dcc_env* env);
+
+/* D = 4 + 2(N-1) + 5M (coverage.py:99-110); share-obs dim is N*D (uav_dcc.py:40-43). */
+DCC_API int dcc_env_obs_dim(const dcc_env* env);
+
+/* Replaces: ShareVecEnv.reset (wrappers.py:167-171,236-238) -> reset_world (coverage.py:64-78).
+ * obs: [E,N,D] float32 device pointer or NULL. */
+DCC_API int dcc_env_reset(dcc_env* env, float* obs, void* stream);
+
+/* Replaces: SubprocVecEnv.step_async/step_wait + worker auto-reset (wrappers.py:97-110,156-165),
+ * DCEnv.step (uav_dcc.py:46-49), MultiAgentEnv.step/_set_action (environment.py:86-110,153-201),
+ * CoverageWorld.step and everything it calls (CoverageWorld.py:57-174), Scenario.reward/
+ * observation/done (coverage.py:80-117).
+ * actions: [E,N,2] device pointer of act_dtype; never written. */
+DCC_API int dcc_env_step(dcc_env* env, const void* actions, int act_dtype, const dcc_env_out* out, void* stream);
+
+/* K fused steps in one launch (the learner-free rollout used for BASELINE config 2).
+ * actions: [K,E,N,2] float32 device pointer, or NULL to draw them in-kernel from the
+ * counter-based generator (uniform [-1,1), keyed by seed, step0+k, env0+e, agent; `env_total`
+ * is the job-wide env count so that shards of one job draw disjoint, reproducible streams).
+ * out arrays carry a leading K dimension; out->obs == NULL skips the obs write. */
+DCC_API int dcc_env_rollout(dcc_env* env, int32_t K, const float* actions, uint64_t seed, uint32_t step0,
+                    int32_t env0, int32_t env_total, const dcc_env_out* out, void* stream);
+
+/* Checkpoint / fixture access to the internal state (device pointers, NULL = skip):
+ * pos [E,N,2] f64, vel [E,N,2] f64, energy [E,M] f32, done [E,M] u8. */
+DCC_API int dcc_env_get_state(dcc_env* env, double* pos, double* vel, float* energy, uint8_t* done, void* stream);
+DCC_API int dcc_env_set_state(dcc_env* env, const double* pos, const double* vel, const float* energy,
+                      const uint8_t* done, void* stream);
+
+/* Algorithmic HBM bytes of one env-step (SURVEY.md section 8d, fp32 I/O contract):
+ * 40N + 11M + 11 + 4*N*D; with_actions=0 drops 8N; with_obs=0 drops 4*N*D. */
+DCC_API int64_t dcc_env_bytes_per_step(int32_t n_agents, int32_t n_pois, int32_t with_actions, int32_t with_obs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCC_ENV_H */

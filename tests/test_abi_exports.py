@@ -1,0 +1,80 @@
+"""CPU-side checks of the C-ABI: the shared library loads without a GPU and exports every symbol
+declared in include/*.h; argument validation fails loudly (no compute calls here)."""
+import ctypes
+import glob
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, PKG
+
+
+def _declared():
+    names = []
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        names += re.findall(r"DCC_API\s+[\w\s\*]+?\b(dcc_\w+)\s*\(", open(h).read())
+    return sorted(set(names))
+
+
+def _libpath():
+    p = os.path.join(PKG, "csrc", "libdcc_hip.so")
+    if not os.path.exists(p):
+        import __graft_entry__ as g
+        g.build()
+    return p
+
+
+def test_header_declares_expected_entry_points():
+    d = _declared()
+    for n in ("dcc_env_create", "dcc_env_step", "dcc_env_reset", "dcc_env_rollout", "dcc_env_destroy",
+              ):
+        assert n in d, n
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_libpath())
+    for n in _declared():
+        assert hasattr(lib, n), "missing export %s" % n
+    assert lib.dcc_abi_version() == 1
+
+
+def test_binding_lists_match_header():
+    import dcc_hip
+    assert set(dcc_hip.EXPORTS) <= set(_declared())
+
+
+def test_create_validates_arguments_and_has_no_cpu_path():
+    import numpy as np
+    import torch
+    import dcc_hip
+    L = dcc_hip.load_library()
+    cfg = dcc_hip.EnvCfg()
+    L.dcc_env_cfg_default(ctypes.byref(cfg))
+    assert cfg.dt == 0.1 and cfg.damping == 0.25 and cfg.rew_done == 1500.0 and cfg.comm_r_scale == 0.9
+    h = ctypes.c_void_p()
+    poi = np.zeros((4, 2))
+    cfg.n_envs, cfg.n_agents, cfg.n_pois = 1, 65, 4
+    cfg.poi_xy = poi.ctypes.data_as(ctypes.c_void_p)
+    assert L.dcc_env_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"n_agents" in L.dcc_last_error()
+    cfg.n_agents, cfg.n_pois = 4, 2000
+    assert L.dcc_env_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    cfg.n_pois, cfg.poi_xy = 4, None
+    assert L.dcc_env_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    if not torch.cuda.is_available():
+        # no device: creation must FAIL (negative code), never fall back to a CPU implementation
+        cfg.poi_xy = poi.ctypes.data_as(ctypes.c_void_p)
+        assert L.dcc_env_create(ctypes.byref(cfg), ctypes.byref(h)) < 0
+        with pytest.raises(dcc_hip.DccError):
+            dcc_hip.HipCoverageEnv(1, 4, 4, poi)
+
+
+def test_bytes_per_step_matches_survey_figures():
+    import dcc_hip
+    # c1 1,787 B, c2 11,851 B, c4 87,563 B, c5 676,363 B
+    assert dcc_hip.bytes_per_step(4, 16) == 1787
+    assert dcc_hip.bytes_per_step(8, 64) == 11851
+    assert dcc_hip.bytes_per_step(16, 256) == 87563
+    assert dcc_hip.bytes_per_step(32, 1024) == 676363
+    assert dcc_hip.bytes_per_step(8, 64, with_actions=False) == 11851 - 64

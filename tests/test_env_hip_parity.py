@@ -1,0 +1,201 @@
+"""-m gpu: the HIP env (through the C-ABI) against (1) the reference's golden vectors and (2) the
+CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): bit-exact connectivity / done masks, PoI energy and PoI-assignment
+indices; positions / rewards / observations within 1e-5 (relative for rewards).  The kernel keeps
+float64 state and the reference's operation order, so in practice positions are bit-exact whenever
+the pull force is off (only + - * / sqrt fma are involved) and within a few ulp when it is on
+(device exp/log1p differ from glibc in the last bits)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_env_files, load_case
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL = 1e-9      # absolute, float64 positions/velocities (spec: 1e-5)
+OBS_TOL = 1e-5      # absolute, float32 observations
+REW_RTOL = 1e-5     # relative, rewards (|R| reaches 2e4 -> float32 ulp 2e-3)
+
+
+def _mk(c, z, E=None):
+    import dcc_hip
+    return dcc_hip.HipCoverageEnv(E or c["E"], c["N"], c["M"], z["poi"], c["r_cover"], c["r_comm"], c["comm_r_scale"],
+                                  c["comm_force_scale"])
+
+
+@pytest.mark.parametrize("path", golden_env_files(), ids=lambda p: os.path.basename(p)[4:-4])
+def test_hip_step_matches_reference_golden(path):
+    z, c = load_case(path)
+    env = _mk(c, z)
+    dev = env.device
+    obs0 = env.reset()
+    assert np.array_equal(obs0[0].cpu().numpy(), z["reset_obs"])
+    actions = torch.from_numpy(z["actions"]).to(dev)
+    obs_steps = list(z["obs_steps"])
+    exact_pos = True
+    for t in range(c["T"]):
+        # terminal state is only observable before the auto-reset: run on a snapshot-able path by
+        # reading the state when the env did not finish, and the outputs otherwise
+        out = env.step(actions[t], env.alloc_out(reward64=True))
+        st = env.get_state()
+        torch.cuda.synchronize()
+        done = out["done"].cpu().numpy()
+        assert np.array_equal(done, z["done"][t]), ("done", t)
+        assert np.array_equal(out["connect"].cpu().numpy(), z["connect"][t]), ("connect", t)
+        assert np.array_equal(out["connect_s"].cpu().numpy(), z["connect_s"][t]), ("connect_s", t)
+        assert np.array_equal(out["assign"].cpu().numpy(), z["assign"][t]), ("assign", t)
+        np.testing.assert_allclose(out["coverage"].cpu().numpy(), z["coverage"][t].astype(np.float32), rtol=0, atol=0)
+        ref_r = z["reward"][t]
+        np.testing.assert_allclose(out["reward64"].cpu().numpy(), ref_r, rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(out["reward"].cpu().numpy(), ref_r, rtol=REW_RTOL, atol=1e-5)
+        live = done == 0
+        pos, vel = st["pos"].cpu().numpy(), st["vel"].cpu().numpy()
+        assert np.abs(pos[live] - z["pos_t"][t][live]).max(initial=0) <= POS_TOL, ("pos", t)
+        assert np.abs(vel[live] - z["vel_t"][t][live]).max(initial=0) <= POS_TOL, ("vel", t)
+        exact_pos &= np.array_equal(pos[live], z["pos_t"][t][live]) and np.array_equal(vel[live], z["vel_t"][t][live])
+        assert np.array_equal(st["energy"].cpu().numpy()[live], z["energy_t"][t][live].astype(np.float32)), ("energy", t)
+        assert np.array_equal(st["done"].cpu().numpy()[live], z["done_t"][t][live]), ("done_t", t)
+        # finished envs were reset to the origin (wrappers.py:104-109)
+        assert not pos[~live].any() and not vel[~live].any() and not st["energy"].cpu().numpy()[~live].any()
+        obs = out["obs"].cpu().numpy()
+        np.testing.assert_allclose(obs.astype(np.float64).reshape(c["E"], -1).sum(1), z["obs_sum"][t], rtol=0,
+                                   atol=1e-5 * obs[0].size)
+        if t in obs_steps:
+            np.testing.assert_allclose(obs, z["obs"][obs_steps.index(t)], rtol=0, atol=OBS_TOL)
+    if c["comm_force_scale"] == 0:
+        assert exact_pos, "force-off trajectories are expected bit-exact in float64"
+    env.close()
+
+
+@pytest.mark.parametrize("N,M,cfs,r_comm", [(8, 64, 0.0, 0.4), (8, 64, 0.5, 0.2), (5, 37, 0.5, 0.3), (16, 256, 0.5, 0.15),
+                                            (32, 1024, 0.5, 0.1), (3, 130, 1.0, 0.3), (64, 70, 0.5, 0.08)])
+def test_hip_step_matches_oracle_random(N, M, cfs, r_comm, oracle_mod):
+    """Seeded random actions, E=33 envs (not a multiple of the 4 envs per workgroup), 40 steps."""
+    E, T = 33, 40
+    rs = np.random.RandomState(N * 1000 + M)
+    poi = rs.uniform(-1, 1, (M, 2))
+    import dcc_hip
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, r_comm, 0.95, cfs)
+    orc = oracle_mod.OracleEnv(E, N, M, poi, 0.2, r_comm, 0.95, cfs)
+    o0 = env.reset().cpu().numpy()
+    assert np.array_equal(o0, orc.reset().astype(np.float32))
+    scale = rs.uniform(0.3, 3.0, (E, 1, 1))  # some envs drift out of bounds and reset
+    bias = rs.uniform(-0.5, 0.5, (E, N, 2))
+    for t in range(T):
+        a = np.clip(rs.uniform(-1, 1, (E, N, 2)) * scale + bias, -1, 1).astype(np.float32)
+        out = env.step(torch.from_numpy(a).to(env.device), env.alloc_out(reward64=True))
+        ref = orc.step(a)
+        for k in ("done", "connect", "connect_s"):
+            assert np.array_equal(out[k].cpu().numpy(), ref[k]), (k, t)
+        assert np.array_equal(out["assign"].cpu().numpy().astype(np.int32), ref["assign"]), ("assign", t)
+        np.testing.assert_allclose(out["reward64"].cpu().numpy(), ref["reward"], rtol=1e-11, atol=1e-8)
+        np.testing.assert_allclose(out["coverage"].cpu().numpy(), ref["coverage"].astype(np.float32), rtol=0, atol=0)
+        np.testing.assert_allclose(out["obs"].cpu().numpy(), ref["obs"].astype(np.float32), rtol=0, atol=OBS_TOL)
+        st, so = env.get_state(), orc.get_state()
+        np.testing.assert_allclose(st["pos"].cpu().numpy(), so["pos"], rtol=0, atol=POS_TOL)
+        np.testing.assert_allclose(st["vel"].cpu().numpy(), so["vel"], rtol=0, atol=POS_TOL)
+        assert np.array_equal(st["energy"].cpu().numpy(), so["energy"].astype(np.float32))
+        assert np.array_equal(st["done"].cpu().numpy(), so["done"])
+    env.close()
+
+
+def test_hip_f64_actions_match_oracle(oracle_mod):
+    E, N, M, T = 7, 8, 64, 30
+    rs = np.random.RandomState(5)
+    poi = rs.uniform(-1, 1, (M, 2))
+    import dcc_hip
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, 0.2, 0.9, 0.5)
+    orc = oracle_mod.OracleEnv(E, N, M, poi, 0.2, 0.2, 0.9, 0.5)
+    env.reset(); orc.reset()
+    for t in range(T):
+        a = rs.uniform(-1, 1, (E, N, 2))
+        out = env.step(torch.from_numpy(a).to(env.device))
+        ref = orc.step(a)
+        assert np.array_equal(out["done"].cpu().numpy(), ref["done"])
+        assert np.array_equal(out["connect_s"].cpu().numpy(), ref["connect_s"])
+        np.testing.assert_allclose(env.get_state()["pos"].cpu().numpy(), orc.get_state()["pos"], rtol=0, atol=POS_TOL)
+
+
+def test_rollout_rng_matches_oracle_and_single_steps(oracle_mod):
+    """K fused steps with the in-kernel generator == oracle driven by the same generator == K
+    single-step launches fed the generated actions."""
+    E, N, M, K = 64, 8, 64, 150
+    import dcc_hip
+    poi = np.load(os.path.join(os.path.dirname(__file__), "golden", "pos_pois.npy"))[:M]
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, 0.4, 0.95, 0.0)
+    env2 = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, 0.4, 0.95, 0.0)
+    orc = oracle_mod.OracleEnv(E, N, M, poi, 0.2, 0.4, 0.95, 0.0)
+    env.reset(); env2.reset(); orc.reset()
+    out = env.rollout(K, seed=1234, step0=7, env0=0, env_total=E)
+    ref = orc.rollout_rng(K, 1234, 7, 0, E, want_obs_last=True)
+    assert np.array_equal(out["done"].cpu().numpy(), ref["done"])
+    np.testing.assert_allclose(out["reward"].cpu().numpy(), ref["reward"], rtol=REW_RTOL, atol=1e-5)
+    np.testing.assert_allclose(out["coverage"].cpu().numpy(), ref["coverage"].astype(np.float32), rtol=0, atol=0)
+    np.testing.assert_allclose(out["obs"][-1].cpu().numpy(), ref["obs_last"].astype(np.float32), rtol=0, atol=OBS_TOL)
+    acts = np.stack([oracle_mod.rng_actions(1234, 7 + k, E, N, 0, E) for k in range(K)])
+    out2 = env2.rollout(K, actions=torch.from_numpy(acts).to(env2.device))
+    for k in ("obs", "reward", "done", "connect", "connect_s", "coverage", "assign"):
+        assert torch.equal(out[k], out2[k]), k
+    s1, s2 = env.get_state(), env2.get_state()
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
+
+
+def test_sharded_envs_equal_single_device_concatenation():
+    """Env shards (what each rank of an N-GPU job runs) reproduce the unsharded batch exactly."""
+    E, N, M, K = 48, 8, 64, 60
+    import dcc_hip
+    poi = np.load(os.path.join(os.path.dirname(__file__), "golden", "pos_pois.npy"))[:M]
+    full = dcc_hip.HipCoverageEnv(E, N, M, poi)
+    full.reset()
+    ref = full.rollout(K, seed=9, env0=0, env_total=E)
+    parts = []
+    for r in range(3):
+        sh = dcc_hip.HipCoverageEnv(E // 3, N, M, poi)
+        sh.reset()
+        parts.append(sh.rollout(K, seed=9, env0=r * (E // 3), env_total=E))
+    for k in ("obs", "reward", "done", "coverage"):
+        assert torch.equal(ref[k], torch.cat([p[k] for p in parts], dim=1)), k
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 size (N=8, M=64, E=4096, T=150): size-independent invariants."""
+    E, N, M, K = 4096, 8, 64, 150
+    import dcc_hip
+    poi = np.load(os.path.join(os.path.dirname(__file__), "golden", "pos_pois.npy"))[:M]
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi)
+    env.reset()
+    out = env.rollout(K, seed=3, out=env.alloc_out(K, obs=True, assign=True, reward64=True))
+    torch.cuda.synchronize()
+    obs = out["obs"]
+    D = env.D
+    H = 4 + 2 * (N - 1)
+    feat = obs[..., H:].reshape(K, E, N, M, 5)
+    energy, m_en, dn = feat[..., 2], feat[..., 3], feat[..., 4]
+    assert bool((m_en == 5.0).all())
+    assert bool(((dn == 1.0) == (energy >= 5.0)).all())          # done <=> energy >= m_energy
+    assert bool((energy == energy.round()).all())                 # integer-valued energy
+    # every agent of an env sees the same PoI energy / done
+    assert bool((energy == energy[:, :, :1]).all()) and bool((dn == dn[:, :, :1]).all())
+    # coverage_rate == popcount(done)/M wherever the env did not reset on that step
+    live = out["done"] == 0
+    cov = dn[:, :, 0].sum(-1) / M
+    assert torch.allclose(cov[live], out["coverage"][live], atol=1e-6)
+    # energy / done monotone between resets
+    e0, e1 = energy[:-1, :, 0], energy[1:, :, 0]
+    keep = (out["done"][1:] == 0)[..., None].expand_as(e0)
+    assert bool((e1[keep] >= e0[keep]).all())
+    # relative positions are consistent: (x_k - x_i) + (x_i - x_k) == 0 up to float32 rounding
+    rel01 = obs[:, :, 0, 4:6]      # x_1 - x_0 as seen by agent 0
+    rel10 = obs[:, :, 1, 4:6]      # x_0 - x_1 as seen by agent 1
+    assert float((rel01 + rel10).abs().max()) < 1e-6
+    # speed clamp and reward decomposition R = N*base + 75*#just  (mod 75 structure not testable
+    # without base; check the bound instead): reward is finite and resets happened only on done
+    vel = obs[..., 0:2]
+    assert float(vel.norm(dim=-1).max()) <= 0.5 + 1e-6
+    assert bool(torch.isfinite(out["reward64"]).all())
+    assert 0 <= int(out["assign"].max()) < N
