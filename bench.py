@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- agent-env-steps/s of the batched coverage-env hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "c2"): 8 UAVs x 64 PoIs x 4096 envs per GPU, random actions,
+env-step HIP kernel only.  A "step" is one batched env step over all E envs of every rank.  Steps
+are issued as fused launches of --steps-per-launch (default T=150, one rollout) env steps, each
+reading its actions [T,E,N,2] from HBM and writing obs [T,E,N,D] + per-step outputs to HBM, i.e.
+the full algorithmic byte contract of SURVEY.md section 8d (11,851 B per env-step at c2).
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the launch stream;
+`cpu_baseline` times the CPU oracle (oracle/dcc_oracle.c, "port") on the host cores, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "dynamic-coverage-control_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def _host_threads():
+    """Threads the host really gives us: affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, budget_s=10.0):
+    """Time the CPU restatement on a bounded sample of the same workload: every host thread steps
+    its own batch of 64 envs in chunks of 25 steps until `budget_s` seconds have passed."""
+    from oracle import oracle
+    oracle.build()
+    cores = _host_threads()
+    E_thr, K = 64, 25
+    o = oracle.OracleEnv(E_thr, N, M, poi, r_cover, r_comm, crs, cfs)
+    o.reset()
+    t0 = time.perf_counter()
+    n1 = 0
+    while time.perf_counter() - t0 < 2.0:
+        o.rollout_rng(K, 0, step0=n1)
+        n1 += K
+    rate1 = E_thr * n1 * N / (time.perf_counter() - t0)
+    o.close()
+    envs = [oracle.OracleEnv(E_thr, N, M, poi, r_cover, r_comm, crs, cfs) for _ in range(cores)]
+    counts = [0] * cores
+    deadline = [0.0]
+
+    def work(i):
+        e = envs[i]
+        e.reset()
+        while time.perf_counter() < deadline[0]:
+            e.rollout_rng(K, 1 + i, step0=counts[i])  # ctypes releases the GIL inside the C call
+            counts[i] += K
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    deadline[0] = t0 + budget_s
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    value = E_thr * sum(counts) * N / dt
+    try:
+        model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": value, "unit": "agent-env-steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle/dcc_oracle.c (C restatement of the reference env, float64): %d threads x %d envs, "
+                      "%.0f s of the c2 workload (N=%d, M=%d; %d env-steps in total) with the same counter-based "
+                      "random actions; single-thread rate %.0f agent-env-steps/s; host CPU: %s"
+                      % (cores, E_thr, dt, N, M, E_thr * sum(counts), rate1, model),
+            "value_1core": rate1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1500)
+    ap.add_argument("--warmup", type=int, default=150)
+    ap.add_argument("--steps-per-launch", type=int, default=150)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--agents", type=int, default=8)
+    ap.add_argument("--pois", type=int, default=64)
+    ap.add_argument("--comm-force-scale", type=float, default=0.0)
+    ap.add_argument("--r-comm", type=float, default=0.4)
+    ap.add_argument("--actions", choices=["hbm", "rng"], default="hbm",
+                    help="hbm: read pre-generated actions [T,E,N,2] (full byte contract); rng: draw in-kernel")
+    ap.add_argument("--no-obs", action="store_true", help="skip the obs write (state-only variant, not the headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the env hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import dcc_hip
+    from oracle import oracle  # only for generating the synthetic action stream + cpu_baseline leg
+
+    E, N, M, T = args.envs, args.agents, args.pois, args.steps_per_launch
+    r_cover, crs, cfs, r_comm = 0.2, 0.95, args.comm_force_scale, args.r_comm
+    poi_all = np.load(os.path.join(PKG, "envs", "mpe", "pos_pois.npy"))
+    if M > len(poi_all):
+        poi_all = np.concatenate([poi_all, np.random.RandomState(2024).uniform(-1, 1, (M - len(poi_all), 2))])
+    poi = poi_all[:M]
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi, r_cover, r_comm, crs, cfs, device=local_rank)
+    env.reset()
+    out = env.alloc_out(T, obs=not args.no_obs, assign=True)
+    actions = None
+    if args.actions == "hbm":
+        acts = np.stack([oracle.rng_actions(0, k, E, N, rank * E, world * E) for k in range(T)])
+        actions = torch.from_numpy(acts).to(dev)
+
+    def launch(k_steps, step0):
+        o = out if k_steps == T else {k: v[:k_steps] for k, v in out.items()}
+        a = actions if (actions is None or k_steps == T) else actions[:k_steps]
+        env.rollout(k_steps, actions=a, seed=0, step0=step0, env0=rank * E, env_total=world * E, out=o)
+
+    def run(n_steps, events=None):
+        done, step0 = 0, 0
+        while done < n_steps:
+            k = min(T, n_steps - done)
+            if events is not None and k == T:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                launch(k, step0)
+                e1.record()
+                events.append((e0, e1))
+            else:
+                launch(k, step0)
+            done += k
+            step0 += k
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    run(args.steps, events)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    value = world * E * N * args.steps / dt
+    res = {
+        "metric": "agent_env_steps_per_sec", "value": value, "unit": "agent-env-steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "c2: %d UAV x %d PoI x %d envs per GPU, random-action env-step HIP kernel only; "
+                               "%d fused env steps per launch, actions %s, obs %s" % (
+                                   N, M, E, T, "read from HBM [T,E,N,2] f32" if actions is not None else "drawn in-kernel",
+                                   "skipped" if args.no_obs else "written to HBM [T,E,N,D] f32"),
+                   "n_agents": N, "n_pois": M, "envs_per_gpu": E, "global_envs": world * E,
+                   "steps_per_launch": T, "comm_force_scale": cfs, "parallelism": "env-shard x%d (no data-path collective)" % world},
+    }
+    if events:
+        ms = [a.elapsed_time(b) for a, b in events]
+        avg_ms = sum(ms) / len(ms)
+        bstep = dcc_hip.bytes_per_step(N, M, with_actions=actions is not None, with_obs=not args.no_obs)
+        alg = bstep * E * T
+        ach = alg / (avg_ms * 1e-3) / 1e9
+        res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "dcc_env_kernel<1,false>", "bytes_per_env_step": bstep,
+                           "launch_ms_avg": avg_ms, "launch_ms_min": min(ms), "launches_timed": len(ms),
+                           "frac_of_achievable_6300": ach / 6300.0}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

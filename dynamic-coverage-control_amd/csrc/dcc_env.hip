@@ -42,9 +42,9 @@ struct KParams {
     int stageC;                 // floats in the per-wave staging window
     int vec_ok;                 // obs rows may be stored as float4
     int use_connect, use_force;
-    int rng;                    // draw actions in-kernel
     unsigned magicN;            // ceil(2^20 / N): p / N == (p * magicN) >> 20 for p < 4096
-    double r_cover, thr, thr_s, thr2, dmax, contact_force, contact_margin;
+    double sq_cover, sq_thr, sq_thr_s, sq_speed;  // radicand bounds of the threshold tests (see kernel)
+    double thr2, dmax, contact_force, contact_margin;
     double dt, keep, max_speed, sens, mass, m_energy;
     double rew_cover, rew_done, rew_out, bound_soft, bound_hard;
     float sens_f, mass_f, dt_f, m_energy_f;
@@ -155,8 +155,16 @@ struct Stager {
     }
 };
 
-template <int PPL, bool ACT64>
-__global__ __launch_bounds__(kBlock) void dcc_env_kernel(const KParams p) {
+// ACT: 0 = float32 actions from HBM, 1 = float64 actions from HBM, 2 = drawn in-kernel (float32).
+// FORCE: the connectivity-preserving pull force (CW:100-140) is compiled in.
+//
+// Exact sqrt-free comparisons: every threshold test on a distance d = sqrt_rn(s) (IEEE, correctly
+// rounded, monotone in s) is rewritten as a test on the radicand s against a host-computed bound
+//   d <= r  <=>  s <= max{ t : sqrt_rn(t) <= r }      d < r  <=>  s <= max{ t : sqrt_rn(t) < r }
+// and min_i sqrt_rn(s_i) == sqrt_rn(min_i s_i), so the results are bit-identical to taking the
+// square roots (the argmin tie rule is handled by an exact slow path, see `near`).
+template <int PPL, int ACT, bool FORCE>
+__global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -169,6 +177,7 @@ __global__ __launch_bounds__(kBlock) void dcc_env_kernel(const KParams p) {
     unsigned char* wbase = smem + ((M * 16 + 15) & ~15) + wid * per_wave;
     double2* apos = reinterpret_cast<double2*>(wbase);
     double2* avel = apos + N;
+    const double* apv = reinterpret_cast<const double*>(wbase);  // flat view: [pos | vel][N][2]
     float* stg = reinterpret_cast<float*>(avel + N);
 
     for (int j = threadIdx.x; j < M; j += kBlock) s_poi[j] = p.poi[j];
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(kBlock) void dcc_env_kernel(const KParams p) {
             float uxf = 0.f, uyf = 0.f;
             double uxd = 0, uyd = 0;
             if (lane < N) {
-                if (p.rng) {
+                if (ACT == 2) {
                     const unsigned long long idx =
                         ((unsigned long long)(p.step0 + (unsigned)k) * (unsigned long long)p.env_total +
                          (unsigned long long)(p.env0 + env)) * (unsigned long long)N + (unsigned long long)lane;
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void dcc_env_kernel(const KParams p) {
                     const unsigned hi = (unsigned)(z >> 40), lo = (unsigned)((z & 0xFFFFFFFFULL) >> 8);
                     uxf = ((float)hi * (1.0f / 8388608.0f) - 1.0f) * p.sens_f;
                     uyf = ((float)lo * (1.0f / 8388608.0f) - 1.0f) * p.sens_f;
-                } else if (ACT64) {
+                } else if (ACT == 1) {
                     const double2 a = reinterpret_cast<const double2*>(p.actions)[ko * N + lane];
                     uxd = a.x * p.sens; uyd = a.y * p.sens;
                 } else {
@@ -242,9 +251,10 @@ __global__ __launch_bounds__(kBlock) void dcc_env_kernel(const KParams p) {
                     bool adj = false, adjs = false;
                     if (pidx < npairs && a != b) {
                         const double2 pa = apos[a], pb = apos[b];
-                        const double d = norm2(pa.x - pb.x, pa.y - pb.y);
-                        adj = d < p.thr;
-                        adjs = adj && (d < p.thr_s);
+                        const double dx = pa.x - pb.x, dy = pa.y - pb.y;
+                        const double s = __builtin_fma(dy, dy, dx * dx);
+                        adj = s <= p.sq_thr;                 // d < r_a + r_b            (CW:77)
+                        adjs = adj && (s <= p.sq_thr_s);     // d < comm_r_scale*(r_a+r_b) (CW:79)
                     }
                     const unsigned long long mA = __ballot(adj), mS = __ballot(adjs);
                     if (lane < N) {
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void dcc_env_kernel(const KParams p) {
                 connect_s = (N == 1) ? true : (N == 2) ? false : (connect && iso == 0ULL);
 
                 // ---- (D) CW:100-140 connectivity-preserving pull force (wave-uniform branch) ----
-                if (p.use_force && !connect_s) {
+                if (FORCE && !connect_s) {
                     double best = 0.0, fx = 0.0, fy = 0.0;
                     int bi = 0;
                     const bool branch1 = (iso != 0ULL);
@@ -315,11 +325,11 @@ __global__ __launch_bounds__(kBlock) void dcc_env_kernel(const KParams p) {
                         const double fax = readlane_f64(fx, a), fay = readlane_f64(fy, a);
                         if (a == b) continue;  // get_connect_force returns [0, 0] (CW:130-131)
                         if (lane == a) {
-                            if (ACT64) { uxd += -fax; uyd += -fay; }
+                            if (ACT == 1) { uxd += -fax; uyd += -fay; }
                             else { uxf = (float)((double)uxf + (-fax)); uyf = (float)((double)uyf + (-fay)); }
                         }
                         if (lane == b) {
-                            if (ACT64) { uxd += fax; uyd += fay; }
+                            if (ACT == 1) { uxd += fax; uyd += fay; }
                             else { uxf = (float)((double)uxf + fax); uyf = (float)((double)uyf + fay); }
                         }
                     }
@@ -329,14 +339,17 @@ __global__ __launch_bounds__(kBlock) void dcc_env_kernel(const KParams p) {
             // ---- (E) CW:142-155 integrate_state ----------------------------------------------
             if (lane < N) {
                 vx = vx * p.keep; vy = vy * p.keep;
-                if (ACT64) {
+                if (ACT == 1) {
                     vx += (uxd / p.mass) * p.dt; vy += (uyd / p.mass) * p.dt;
                 } else {
                     const float ax = (uxf / p.mass_f) * p.dt_f, ay = (uyf / p.mass_f) * p.dt_f;
                     vx += (double)ax; vy += (double)ay;
                 }
-                const double speed = __builtin_sqrt(vx * vx + vy * vy);
-                if (speed > p.max_speed) { vx = vx / speed * p.max_speed; vy = vy / speed * p.max_speed; }
+                const double s2 = vx * vx + vy * vy;      // np.square + np.square: no fusion (CW:150)
+                if (s2 > p.sq_speed) {                    // sqrt(s2) > max_speed
+                    const double speed = __builtin_sqrt(s2);
+                    vx = vx / speed * p.max_speed; vy = vy / speed * p.max_speed;
+                }
                 px += vx * p.dt; py += vy * p.dt;
                 apos[lane] = make_double2(px, py);
                 avel[lane] = make_double2(vx, vy);
@@ -351,12 +364,28 @@ __global__ __launch_bounds__(kBlock) void dcc_env_kernel(const KParams p) {
                 const int j = q * 64 + lane;
                 const bool valid = j < M;
                 int cnt = 0, amin = 0;
-                double dmin = 0.0;
+                double smin = 1.7976931348623157e308;
+                bool near = false;
+#pragma unroll 4
                 for (int i = 0; i < N; ++i) {
                     const double2 xa = apos[i];
-                    const double d = norm2(pjx[q] - xa.x, pjy[q] - xa.y);
-                    cnt += (d <= p.r_cover) ? 1 : 0;
-                    if (i == 0 || d < dmin) { dmin = d; amin = i; }
+                    const double dx = pjx[q] - xa.x, dy = pjy[q] - xa.y;
+                    const double s = __builtin_fma(dy, dy, dx * dx);
+                    cnt += (s <= p.sq_cover) ? 1 : 0;      // ||p_j - x_i|| <= r_cover (CW:164-165)
+                    if (s < smin) {
+                        // an earlier agent within a few ulp above the new minimum could tie on the
+                        // rounded distance: resolve exactly below
+                        near = near || (smin <= s * 1.0000000000000009);
+                        smin = s; amin = i;
+                    }
+                }
+                if (near && p.assign) {  // exact first-minimum on the rounded distances (practically never taken)
+                    double dmn = 0.0;
+                    for (int i = 0; i < N; ++i) {
+                        const double2 xa = apos[i];
+                        const double d = norm2(pjx[q] - xa.x, pjy[q] - xa.y);
+                        if (i == 0 || d < dmn) { dmn = d; amin = i; }
+                    }
                 }
                 bool dn = (dmask >> q) & 1u, just = false;
                 if (valid && !dn) {
@@ -365,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void dcc_env_kernel(const KParams p) {
                 }
                 n_done += __popcll(__ballot(valid && dn));
                 n_just += __popcll(__ballot(just));
-                if (valid && !dn) part -= dmin;
+                if (valid && !dn) part -= __builtin_sqrt(smin);
                 if (valid && p.assign) p.assign[ko * M + j] = (uint8_t)amin;
             }
             bool oob = false;
@@ -411,21 +440,20 @@ __global__ __launch_bounds__(kBlock) void dcc_env_kernel(const KParams p) {
             st.gout = p.obs + ko * (size_t)p.L;
             for (int i = 0; i < N; ++i) {
                 const double2 xi = apos[i];
-                // header: vel(2) pos(2) (x_k - x_i for k != i)
+                // header: vel(2) pos(2) (x_k - x_i for k != i); branch-free per lane:
+                //   f<2 -> avel[i][f&1]; f<4 -> apos[i][f&1]; else apos[k'][f&1] - x_i[f&1], k' skips i
                 for (int f0 = 0; f0 < H; f0 += 64) {
                     const int len = (H - f0) < 64 ? (H - f0) : 64;
                     float* dst = st.reserve(i * D + f0, len, lane);
                     const int f = f0 + lane;
                     if (f < H) {
-                        double v;
-                        if (f < 2) { const double2 w = avel[i]; v = f ? w.y : w.x; }
-                        else if (f < 4) { v = (f == 3) ? xi.y : xi.x; }
-                        else {
-                            const int kk = (f - 4) >> 1, c = (f - 4) & 1;
-                            const double2 xo = apos[kk + (kk >= i ? 1 : 0)];
-                            v = c ? (xo.y - xi.y) : (xo.x - xi.x);
-                        }
-                        dst[lane] = (float)v;
+                        const int c = f & 1;
+                        const int kk = (f - 4) >> 1;
+                        const bool rel = f >= 4;
+                        const int src = rel ? (kk + (kk >= i ? 1 : 0)) : (f < 2 ? N + i : i);
+                        const double val = apv[2 * src + c];
+                        const double sub = rel ? (c ? xi.y : xi.x) : 0.0;
+                        dst[lane] = (float)(val - sub);
                     }
                 }
 #pragma unroll
@@ -498,19 +526,27 @@ namespace {
 
 typedef void (*kernel_fn)(const KParams);
 
-template <bool ACT64>
-kernel_fn pick_kernel(int ppl) {
+template <int ACT, bool FORCE>
+kernel_fn pick_ppl(int ppl) {
     switch (ppl) {
-        case 1: return dcc_env_kernel<1, ACT64>;
-        case 2: return dcc_env_kernel<2, ACT64>;
-        case 4: return dcc_env_kernel<4, ACT64>;
-        case 8: return dcc_env_kernel<8, ACT64>;
-        default: return dcc_env_kernel<16, ACT64>;
+        case 1: return dcc_env_kernel<1, ACT, FORCE>;
+        case 2: return dcc_env_kernel<2, ACT, FORCE>;
+        case 4: return dcc_env_kernel<4, ACT, FORCE>;
+        case 8: return dcc_env_kernel<8, ACT, FORCE>;
+        default: return dcc_env_kernel<16, ACT, FORCE>;
     }
 }
 
-int launch(dcc_env* env, KParams& p, bool act64, void* stream) {
-    kernel_fn fn = act64 ? pick_kernel<true>(env->PPL) : pick_kernel<false>(env->PPL);
+kernel_fn pick_kernel(int ppl, int act, bool force) {
+    if (force) {
+        return act == 0 ? pick_ppl<0, true>(ppl) : act == 1 ? pick_ppl<1, true>(ppl) : pick_ppl<2, true>(ppl);
+    }
+    return act == 0 ? pick_ppl<0, false>(ppl) : act == 1 ? pick_ppl<1, false>(ppl) : pick_ppl<2, false>(ppl);
+}
+
+// act: 0 = f32 actions, 1 = f64 actions, 2 = in-kernel generator
+int launch(dcc_env* env, KParams& p, int act, void* stream) {
+    kernel_fn fn = pick_kernel(env->PPL, act, p.use_force != 0);
     const int grid = (p.E + kWavesPerBlock - 1) / kWavesPerBlock;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (env->lds_bytes > 64 * 1024) {
@@ -520,6 +556,20 @@ int launch(dcc_env* env, KParams& p, bool act64, void* stream) {
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), env->lds_bytes, s, p);
     HIP_TRY(hipGetLastError());
     return DCC_OK;
+}
+
+// max{ t >= 0 : sqrt_rn(t) <= r } (strict = false) or max{ t : sqrt_rn(t) < r } (strict = true);
+// -1 when no t >= 0 qualifies.  Host sqrt is IEEE correctly rounded, like the device's.
+double radicand_bound(double r, bool strict) {
+    auto ok = [&](double t) { const double q = std::sqrt(t); return strict ? (q < r) : (q <= r); };
+    if (!(r >= 0.0) || !ok(0.0)) return -1.0;
+    const double big = 1.7976931348623157e308;
+    if (std::isinf(r)) return big;
+    double t = r * r;
+    if (!std::isfinite(t)) t = big;
+    while (!ok(t)) t = std::nextafter(t, 0.0);
+    while (t < big && ok(std::nextafter(t, INFINITY))) t = std::nextafter(t, INFINITY);
+    return t;
 }
 
 int fill_out(KParams& p, const dcc_env_out* out) {
@@ -618,9 +668,10 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     const double contact_force = 1e+2 * c->comm_force_scale;  // core.py:109 scaled at CW:16
     p.use_force = contact_force > 0;
     p.magicN = ((1u << 20) + (unsigned)N - 1u) / (unsigned)N;
-    p.r_cover = c->r_cover;
-    p.thr = c->r_comm + c->r_comm;                          // CW:77
-    p.thr_s = c->comm_r_scale * (c->r_comm + c->r_comm);    // CW:79
+    p.sq_cover = radicand_bound(c->r_cover, false);                                   // d <= r_cover (CW:165)
+    p.sq_thr = radicand_bound(c->r_comm + c->r_comm, true);                           // d <  r_a + r_b (CW:77)
+    p.sq_thr_s = radicand_bound(c->comm_r_scale * (c->r_comm + c->r_comm), true);     // CW:79
+    p.sq_speed = radicand_bound(c->max_speed, false);                                 // speed > max_speed (CW:151)
     p.thr2 = c->comm_r_scale * 2 * c->r_comm;               // CW:119 (its own rounding order)
     p.dmax = (c->r_comm + c->r_comm) * c->comm_r_scale;     // CW:134
     p.contact_force = contact_force; p.contact_margin = c->contact_margin;
@@ -674,7 +725,7 @@ int dcc_env_reset(dcc_env* e, float* obs, void* stream) {
     std::memset(&o, 0, sizeof(o));
     o.obs = obs;
     fill_out(p, &o);
-    return launch(e, p, false, stream);
+    return launch(e, p, 0, stream);
 }
 
 int dcc_env_step(dcc_env* e, const void* actions, int act_dtype, const dcc_env_out* out, void* stream) {
@@ -685,9 +736,9 @@ int dcc_env_step(dcc_env* e, const void* actions, int act_dtype, const dcc_env_o
     if (reinterpret_cast<uintptr_t>(actions) & align) return fail(DCC_EINVAL, "dcc_env_step: actions pointer misaligned");
     DeviceGuard guard(e->device);
     KParams p = e->base;
-    p.mode = 0; p.K = 1; p.rng = 0; p.actions = actions;
+    p.mode = 0; p.K = 1; p.actions = actions;
     fill_out(p, out);
-    return launch(e, p, act_dtype == DCC_ACT_F64, stream);
+    return launch(e, p, act_dtype == DCC_ACT_F64 ? 1 : 0, stream);
 }
 
 int dcc_env_rollout(dcc_env* e, int32_t K, const float* actions, uint64_t seed, uint32_t step0, int32_t env0,
@@ -699,10 +750,10 @@ int dcc_env_rollout(dcc_env* e, int32_t K, const float* actions, uint64_t seed, 
         return fail(DCC_EINVAL, "dcc_env_rollout: env0/env_total do not cover this shard");
     DeviceGuard guard(e->device);
     KParams p = e->base;
-    p.mode = 0; p.K = K; p.rng = actions ? 0 : 1; p.actions = actions;
+    p.mode = 0; p.K = K; p.actions = actions;
     p.seed = seed; p.step0 = step0; p.env0 = env0; p.env_total = env_total;
     fill_out(p, out);
-    return launch(e, p, false, stream);
+    return launch(e, p, actions ? 0 : 2, stream);
 }
 
 int dcc_env_get_state(dcc_env* e, double* pos, double* vel, float* energy, uint8_t* done, void* stream) {
