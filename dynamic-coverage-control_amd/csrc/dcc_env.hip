@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -34,12 +35,12 @@ namespace {
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = 64 * kWavesPerBlock;
 constexpr int kTileFloats = 5 * 64;  // one PoI tile of one agent row: 64 PoIs x 5 features
+constexpr int kStageC = 2048;        // floats in the per-wave LDS staging window (8 KB)
 
 struct KParams {
     int E, N, M, D, L, H;       // L = N*D floats per env, H = 4 + 2(N-1) header floats per agent row
     int K;                      // fused steps in this launch
     int mode;                   // 0 = step, 1 = reset
-    int stageC;                 // floats in the per-wave staging window
     int vec_ok;                 // obs rows may be stored as float4
     int use_connect, use_force;
     unsigned magicN;            // ceil(2^20 / N): p / N == (p * magicN) >> 20 for p < 4096
@@ -120,7 +121,7 @@ __device__ __forceinline__ double logaddexp0(double y) {
 struct Stager {
     float* stg;    // LDS, 16-byte aligned, C floats
     float* gout;   // HBM base of this env-step's obs block
-    int C, w0;     // w0 = flat index held by stg[0] (multiple of 4 in vector mode)
+    int w0;        // flat index held by stg[0] (multiple of 4 in vector mode)
     int vec;
 
     // Stream out [w0, end) and slide the window so that `s` (next flat index to be produced) fits.
@@ -132,12 +133,12 @@ struct Stager {
             const int nv = n >> 2;
             const float4* s4 = reinterpret_cast<const float4*>(stg);
             float4* g4 = reinterpret_cast<float4*>(gout + w0);
-            int v = lane;
-            for (; v + 192 < nv; v += 256) {
-                float4 x0 = s4[v], x1 = s4[v + 64], x2 = s4[v + 128], x3 = s4[v + 192];
-                g4[v] = x0; g4[v + 64] = x1; g4[v + 128] = x2; g4[v + 192] = x3;
+            // trip count is wave-uniform (static in the specialised kernels -> straight-line code)
+#pragma unroll 4
+            for (int b = 0; b < nv; b += 64) {
+                const int v = b + lane;
+                if (v < nv) g4[v] = s4[v];
             }
-            for (; v < nv; v += 64) g4[v] = s4[v];
         } else {
             for (int v = lane; v < n; v += 64) gout[w0 + v] = stg[v];
         }
@@ -150,7 +151,7 @@ struct Stager {
         wave_fence();
     }
     __device__ __forceinline__ float* reserve(int s, int len, int lane) {
-        if (s + len - w0 > C) flush(s, lane);
+        if (s + len - w0 > kStageC) flush(s, lane);
         return stg + (s - w0);
     }
 };
@@ -163,17 +164,26 @@ struct Stager {
 //   d <= r  <=>  s <= max{ t : sqrt_rn(t) <= r }      d < r  <=>  s <= max{ t : sqrt_rn(t) < r }
 // and min_i sqrt_rn(s_i) == sqrt_rn(min_i s_i), so the results are bit-identical to taking the
 // square roots (the argmin tie rule is handled by an exact slow path, see `near`).
-template <int PPL, int ACT, bool FORCE>
+//
+// NC / MC > 0: N and M are compile-time constants (the BASELINE configs): every loop over agents
+// and PoI tiles unrolls, the staging-window flush points become static and the scalar unit (one per
+// CU, shared by the 16 resident waves) is relieved of loop control and index arithmetic.  NC = 0 is
+// the generic runtime-size kernel.
+template <int PPL, int ACT, bool FORCE, int NC, int MC>
 __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int env = blockIdx.x * kWavesPerBlock + wid;
-    const int N = p.N, M = p.M, D = p.D, H = p.H;
+    constexpr bool SPEC = NC > 0;
+    const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
+    const int H = 4 + 2 * (N - 1), D = H + 5 * M, L = N * D;
+    constexpr int UNR_F = SPEC ? 4 : 2;                    // unroll of the energy-pass loop over agents
+    constexpr int UNR_O = SPEC ? ((NC <= 8 && !FORCE) ? NC : 2) : 1;   // unroll of the observation-row loop (static flush points when full)
 
     // LDS carve: PoI table shared by the block, then per wave: apos[N], avel[N], staging[C].
     double2* s_poi = reinterpret_cast<double2*>(smem);
-    const int per_wave = N * 32 + p.stageC * 4;
+    const int per_wave = N * 32 + kStageC * 4;
     unsigned char* wbase = smem + ((M * 16 + 15) & ~15) + wid * per_wave;
     double2* apos = reinterpret_cast<double2*>(wbase);
     double2* avel = apos + N;
@@ -212,8 +222,43 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
     }
     if (lane < N) { apos[lane] = make_double2(px, py); avel[lane] = make_double2(vx, vy); }
     wave_fence();
+    // Specialised kernels keep the float32 (p_j - x_i) of the energy pass for the observation rows
+    // (identical values: same float64 subtraction, same cast) instead of recomputing them.
+    constexpr bool CACHE = SPEC && !FORCE && (NC * PPL <= 8);
+    constexpr int NCACHE = CACHE ? NC * PPL : 1;
+    float cdx[NCACHE], cdy[NCACHE];
+    if (CACHE) {
+#pragma unroll
+        for (int q = 0; q < PPL; ++q)
+#pragma unroll
+            for (int i = 0; i < (CACHE ? NC : 0); ++i) {
+                const double2 xa = apos[i];
+                cdx[q * NC + i] = (float)(pjx[q] - xa.x); cdy[q * NC + i] = (float)(pjy[q] - xa.y);
+            }
+    }
+    // Every value loaded from HBM above is consumed here, once: the step loop then contains no
+    // use of a pending load, so the compiler never has to drain the obs stores (s_waitcnt vmcnt(0))
+    // of earlier steps in the middle of a step.
+    asm volatile("" : "+v"(px), "+v"(py), "+v"(vx), "+v"(vy), "+v"(dmask));
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) asm volatile("" : "+v"(en[q]));
+
+    // Actions from HBM are fetched for a whole chunk of steps at once: lane (s*N + i) holds the
+    // action of agent i at step (chunk start + s); ACT_R loads per lane -> ACT_R*(64/N) steps per
+    // chunk, so that the unavoidable vmcnt wait (which also drains this wave's older obs stores)
+    // is paid once per chunk instead of once per step.
+    constexpr int ACT_R = 2;
+    const int steps_per_load = 64 / N;                 // >= 1 because N <= 64
+    const int chunk = ACT_R * steps_per_load;
+    const int my_s = SPEC ? (lane / (SPEC ? NC : 1)) : (int)(((unsigned)lane * p.magicN) >> 20);   // lane / N
+    const int my_i = lane - my_s * N;                            // lane % N
+    float2 abuf_f[ACT_R];
+    double2 abuf_d[ACT_R];
+#pragma unroll
+    for (int r = 0; r < ACT_R; ++r) { abuf_f[r] = make_float2(0.f, 0.f); abuf_d[r] = make_double2(0.0, 0.0); }
 
     const unsigned long long fullN = (N >= 64) ? ~0ULL : ((1ULL << N) - 1ULL);
+    int kc = 0, r_sel = 0, s_sel = 0;  // position inside the current action chunk
 
     for (int k = 0; k < p.K; ++k) {
         const size_t ko = (size_t)k * p.E + env;  // index of this env-step in [K,E] outputs
@@ -221,8 +266,8 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
             // ---- (A) EN:153-201 u = action; u *= 5.0 in the action's dtype ------------------
             float uxf = 0.f, uyf = 0.f;
             double uxd = 0, uyd = 0;
-            if (lane < N) {
-                if (ACT == 2) {
+            if (ACT == 2) {
+                if (lane < N) {
                     const unsigned long long idx =
                         ((unsigned long long)(p.step0 + (unsigned)k) * (unsigned long long)p.env_total +
                          (unsigned long long)(p.env0 + env)) * (unsigned long long)N + (unsigned long long)lane;
@@ -230,12 +275,42 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
                     const unsigned hi = (unsigned)(z >> 40), lo = (unsigned)((z & 0xFFFFFFFFULL) >> 8);
                     uxf = ((float)hi * (1.0f / 8388608.0f) - 1.0f) * p.sens_f;
                     uyf = ((float)lo * (1.0f / 8388608.0f) - 1.0f) * p.sens_f;
-                } else if (ACT == 1) {
-                    const double2 a = reinterpret_cast<const double2*>(p.actions)[ko * N + lane];
-                    uxd = a.x * p.sens; uyd = a.y * p.sens;
+                }
+            } else {
+                if (kc == chunk) { kc = 0; r_sel = 0; s_sel = 0; }
+                if (kc == 0) {
+#pragma unroll
+                    for (int r = 0; r < ACT_R; ++r) {
+                        const int ks = k + r * steps_per_load + my_s;
+                        if (my_s < steps_per_load && ks < p.K) {
+                            const size_t ai = ((size_t)ks * p.E + env) * N + my_i;
+                            if (ACT == 1) abuf_d[r] = reinterpret_cast<const double2*>(p.actions)[ai];
+                            else abuf_f[r] = reinterpret_cast<const float2*>(p.actions)[ai];
+                        }
+                    }
+                    // consume the loads inside this branch: the wait (which also drains this wave's
+                    // older stores) is then paid only on chunk boundaries
+#pragma unroll
+                    for (int r = 0; r < ACT_R; ++r) {
+                        if (ACT == 1) asm volatile("" : "+v"(abuf_d[r].x), "+v"(abuf_d[r].y));
+                        else asm volatile("" : "+v"(abuf_f[r].x), "+v"(abuf_f[r].y));
+                    }
+                }
+                if (s_sel == steps_per_load) { s_sel = 0; ++r_sel; }
+                const int src = s_sel * N + lane;  // lane holding (step kc, agent = lane)
+                ++kc; ++s_sel;
+                if (ACT == 1) {
+                    double2 a = abuf_d[0];
+#pragma unroll
+                    for (int r = 1; r < ACT_R; ++r) if (r_sel == r) a = abuf_d[r];
+                    const double axd = __shfl(a.x, src & 63, 64), ayd = __shfl(a.y, src & 63, 64);
+                    if (lane < N) { uxd = axd * p.sens; uyd = ayd * p.sens; }
                 } else {
-                    const float2 a = reinterpret_cast<const float2*>(p.actions)[ko * N + lane];
-                    uxf = a.x * p.sens_f; uyf = a.y * p.sens_f;
+                    float2 a = abuf_f[0];
+#pragma unroll
+                    for (int r = 1; r < ACT_R; ++r) if (r_sel == r) a = abuf_f[r];
+                    const float axf = __shfl(a.x, src & 63, 64), ayf = __shfl(a.y, src & 63, 64);
+                    if (lane < N) { uxf = axf * p.sens_f; uyf = ayf * p.sens_f; }
                 }
             }
 
@@ -246,7 +321,7 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
                 const int npairs = N * N;
                 for (int r0 = 0; r0 < npairs; r0 += 64) {
                     const int pidx = r0 + lane;
-                    const int a = (int)(((unsigned)pidx * p.magicN) >> 20);
+                    const int a = SPEC ? (pidx / (SPEC ? NC : 1)) : (int)(((unsigned)pidx * p.magicN) >> 20);
                     const int b = pidx - a * N;
                     bool adj = false, adjs = false;
                     if (pidx < npairs && a != b) {
@@ -342,7 +417,9 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
                 if (ACT == 1) {
                     vx += (uxd / p.mass) * p.dt; vy += (uyd / p.mass) * p.dt;
                 } else {
-                    const float ax = (uxf / p.mass_f) * p.dt_f, ay = (uyf / p.mass_f) * p.dt_f;
+                    float ax = uxf, ay = uyf;
+                    if (p.mass_f != 1.0f) { ax = ax / p.mass_f; ay = ay / p.mass_f; }   // x / 1.0f == x exactly
+                    ax *= p.dt_f; ay *= p.dt_f;
                     vx += (double)ax; vy += (double)ay;
                 }
                 const double s2 = vx * vx + vy * vy;      // np.square + np.square: no fusion (CW:150)
@@ -366,10 +443,11 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
                 int cnt = 0, amin = 0;
                 double smin = 1.7976931348623157e308;
                 bool near = false;
-#pragma unroll 4
+#pragma unroll UNR_F
                 for (int i = 0; i < N; ++i) {
                     const double2 xa = apos[i];
                     const double dx = pjx[q] - xa.x, dy = pjy[q] - xa.y;
+                    if (CACHE) { cdx[q * NC + i] = (float)dx; cdy[q * NC + i] = (float)dy; }
                     const double s = __builtin_fma(dy, dy, dx * dx);
                     cnt += (s <= p.sq_cover) ? 1 : 0;      // ||p_j - x_i|| <= r_cover (CW:164-165)
                     if (s < smin) {
@@ -429,6 +507,12 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) en[q] = 0.f;
                 if (lane < N) { apos[lane] = make_double2(0.0, 0.0); avel[lane] = make_double2(0.0, 0.0); }
+                if (CACHE) {
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                        for (int i = 0; i < (CACHE ? NC : 0); ++i) { cdx[q * NC + i] = (float)pjx[q]; cdy[q * NC + i] = (float)pjy[q]; }
+                }
                 wave_fence();
             }
         }
@@ -436,8 +520,9 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
         // ---- (G) SC:99-110 observation rows, streamed through the LDS staging window ----------
         if (p.obs) {
             Stager st;
-            st.stg = stg; st.C = p.stageC; st.w0 = 0; st.vec = p.vec_ok;
-            st.gout = p.obs + ko * (size_t)p.L;
+            st.stg = stg; st.w0 = 0; st.vec = SPEC ? 1 : p.vec_ok;
+            st.gout = p.obs + ko * (size_t)L;
+#pragma unroll UNR_O
             for (int i = 0; i < N; ++i) {
                 const double2 xi = apos[i];
                 // header: vel(2) pos(2) (x_k - x_i for k != i); branch-free per lane:
@@ -463,8 +548,8 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
                         float* dst = st.reserve(i * D + H + q * kTileFloats, 5 * cntj, lane);
                         if (lane < cntj) {
                             float* d5 = dst + 5 * lane;
-                            d5[0] = (float)(pjx[q] - xi.x);
-                            d5[1] = (float)(pjy[q] - xi.y);
+                            d5[0] = CACHE ? cdx[CACHE ? q * NC + i : 0] : (float)(pjx[q] - xi.x);
+                            d5[1] = CACHE ? cdy[CACHE ? q * NC + i : 0] : (float)(pjy[q] - xi.y);
                             d5[2] = en[q];
                             d5[3] = p.m_energy_f;
                             d5[4] = ((dmask >> q) & 1u) ? 1.f : 0.f;
@@ -472,7 +557,7 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
                     }
                 }
             }
-            st.flush(p.L, lane);
+            st.flush(L, lane);
         }
     }
 
@@ -520,6 +605,7 @@ struct dcc_env {
     float* d_energy = nullptr;
     uint8_t* d_done = nullptr;
     size_t lds_bytes = 0;
+    bool no_spec = false;
 };
 
 namespace {
@@ -529,15 +615,31 @@ typedef void (*kernel_fn)(const KParams);
 template <int ACT, bool FORCE>
 kernel_fn pick_ppl(int ppl) {
     switch (ppl) {
-        case 1: return dcc_env_kernel<1, ACT, FORCE>;
-        case 2: return dcc_env_kernel<2, ACT, FORCE>;
-        case 4: return dcc_env_kernel<4, ACT, FORCE>;
-        case 8: return dcc_env_kernel<8, ACT, FORCE>;
-        default: return dcc_env_kernel<16, ACT, FORCE>;
+        case 1: return dcc_env_kernel<1, ACT, FORCE, 0, 0>;
+        case 2: return dcc_env_kernel<2, ACT, FORCE, 0, 0>;
+        case 4: return dcc_env_kernel<4, ACT, FORCE, 0, 0>;
+        case 8: return dcc_env_kernel<8, ACT, FORCE, 0, 0>;
+        default: return dcc_env_kernel<16, ACT, FORCE, 0, 0>;
     }
 }
 
-kernel_fn pick_kernel(int ppl, int act, bool force) {
+// compile-time (N, M) specialisations: BASELINE configs c1 (4,16), shipped (4,20), c2/c3 (8,64), c4 (16,256)
+template <int ACT, bool FORCE>
+kernel_fn pick_spec(int n, int m) {
+    if (n == 8 && m == 64) return dcc_env_kernel<1, ACT, FORCE, 8, 64>;
+    if (n == 4 && m == 16) return dcc_env_kernel<1, ACT, FORCE, 4, 16>;
+    if (n == 4 && m == 20) return dcc_env_kernel<1, ACT, FORCE, 4, 20>;
+    if (n == 16 && m == 256) return dcc_env_kernel<4, ACT, FORCE, 16, 256>;
+    return nullptr;
+}
+
+kernel_fn pick_kernel(int ppl, int act, bool force, int n, int m, bool allow_spec) {
+    kernel_fn f = nullptr;
+    if (allow_spec) {
+        if (force) f = act == 0 ? pick_spec<0, true>(n, m) : act == 1 ? pick_spec<1, true>(n, m) : pick_spec<2, true>(n, m);
+        else f = act == 0 ? pick_spec<0, false>(n, m) : act == 1 ? pick_spec<1, false>(n, m) : pick_spec<2, false>(n, m);
+        if (f) return f;
+    }
     if (force) {
         return act == 0 ? pick_ppl<0, true>(ppl) : act == 1 ? pick_ppl<1, true>(ppl) : pick_ppl<2, true>(ppl);
     }
@@ -546,7 +648,9 @@ kernel_fn pick_kernel(int ppl, int act, bool force) {
 
 // act: 0 = f32 actions, 1 = f64 actions, 2 = in-kernel generator
 int launch(dcc_env* env, KParams& p, int act, void* stream) {
-    kernel_fn fn = pick_kernel(env->PPL, act, p.use_force != 0);
+    // specialised kernels assume float4-aligned obs rows; DCC_NO_SPEC=1 forces the generic kernel (tests)
+    const bool allow_spec = (p.obs == nullptr || p.vec_ok) && !env->no_spec;
+    kernel_fn fn = pick_kernel(env->PPL, act, p.use_force != 0, p.N, p.M, allow_spec);
     const int grid = (p.E + kWavesPerBlock - 1) / kWavesPerBlock;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (env->lds_bytes > 64 * 1024) {
@@ -663,7 +767,6 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     std::memset(&p, 0, sizeof(p));
     p.E = E; p.N = N; p.M = M; p.D = e->D; p.L = e->L; p.H = 4 + 2 * (N - 1);
     p.K = 1; p.mode = 0;
-    p.stageC = 2048;
     p.use_connect = c->comm_r_scale > 0;
     const double contact_force = 1e+2 * c->comm_force_scale;  // core.py:109 scaled at CW:16
     p.use_force = contact_force > 0;
@@ -682,7 +785,8 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     p.sens_f = (float)c->sensitivity; p.mass_f = (float)c->mass; p.dt_f = (float)c->dt; p.m_energy_f = (float)c->m_energy;
     p.env0 = 0; p.env_total = E;
 
-    e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)p.stageC * 4);
+    { const char* ns = std::getenv("DCC_NO_SPEC"); e->no_spec = ns && ns[0] == '1'; }
+    e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);
 
     auto cleanup = [&](int code, const std::string& m) { dcc_env_destroy(e); return fail(code, m); };
     hipError_t err;
@@ -721,6 +825,20 @@ int dcc_env_reset(dcc_env* e, float* obs, void* stream) {
     DeviceGuard guard(e->device);
     KParams p = e->base;
     p.mode = 1; p.K = 1;
+    dcc_env_out o;
+    std::memset(&o, 0, sizeof(o));
+    o.obs = obs;
+    fill_out(p, &o);
+    return launch(e, p, 0, stream);
+}
+
+// Profiling aid (not in the public header): K repetitions of the observation producer only
+// (reset state, no physics) -- isolates the LDS staging + HBM store pipeline.
+__attribute__((visibility("default"))) int dcc_debug_obs_only(dcc_env* e, int32_t K, float* obs, void* stream) {
+    if (!e || K < 1) return fail(DCC_EINVAL, "dcc_debug_obs_only: bad argument");
+    DeviceGuard guard(e->device);
+    KParams p = e->base;
+    p.mode = 1; p.K = K;
     dcc_env_out o;
     std::memset(&o, 0, sizeof(o));
     o.obs = obs;

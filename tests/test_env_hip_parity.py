@@ -27,9 +27,15 @@ def _mk(c, z, E=None):
                                   c["comm_force_scale"])
 
 
+@pytest.mark.parametrize("nospec", ["0", "1"], ids=["spec", "generic"])
 @pytest.mark.parametrize("path", golden_env_files(), ids=lambda p: os.path.basename(p)[4:-4])
-def test_hip_step_matches_reference_golden(path):
+def test_hip_step_matches_reference_golden(path, nospec, monkeypatch):
+    """nospec=1 forces the generic runtime-size kernel where a compile-time (N, M) specialisation
+    exists (BASELINE configs); both must reproduce the reference."""
     z, c = load_case(path)
+    if nospec == "1" and (c["N"], c["M"]) not in ((8, 64), (4, 16), (4, 20), (16, 256)):
+        pytest.skip("no specialised kernel for this size: generic path already covered")
+    monkeypatch.setenv("DCC_NO_SPEC", nospec)
     env = _mk(c, z)
     dev = env.device
     obs0 = env.reset()
