@@ -205,8 +205,17 @@ def main():
         bstep = dcc_hip.bytes_per_step(N, M, with_actions=actions is not None, with_obs=not args.no_obs)
         alg = bstep * E * T
         ach = alg / (avg_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the committed PMC passes, when they describe this workload
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic_c2.json")))
+            w = tj["workload"]
+            if (w["n_agents"], w["n_pois"], w["envs"], w["steps_per_launch"]) == (N, M, E, T) and \
+                    (w["actions"] == "hbm") == (actions is not None) and not args.no_obs:
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
                            "kernel": "dcc_env_kernel<1,false>", "bytes_per_env_step": bstep,
                            "launch_ms_avg": avg_ms, "launch_ms_min": min(ms), "launches_timed": len(ms),
                            "frac_of_achievable_6300": ach / 6300.0}
