@@ -1,0 +1,43 @@
+"""Diagonal Gaussian action head (reference: algos/algo_utils/distributions.py:31-41,72-92,108-119):
+mean = Linear(H, A) (orthogonal init, gain cfg.gain), state-independent log-std parameter (zeros)."""
+import math
+
+import torch
+import torch.nn as nn
+
+from .util import init
+
+
+class AddBias(nn.Module):
+    """Holds the log-std as `_bias` of shape [A, 1] (the reference's parameter name and shape)."""
+
+    def __init__(self, bias):
+        super().__init__()
+        self._bias = nn.Parameter(bias.unsqueeze(1))
+
+    def forward(self, x):
+        return x + self._bias.t().view(1, -1)
+
+
+class FixedNormal(torch.distributions.Normal):
+    def log_probs(self, actions):
+        return super().log_prob(actions).sum(-1, keepdim=True)
+
+    def mode(self):
+        return self.mean
+
+
+class DiagGaussian(nn.Module):
+    def __init__(self, num_inputs, num_outputs, use_orthogonal=True, gain=0.01):
+        super().__init__()
+        init_method = nn.init.orthogonal_ if use_orthogonal else nn.init.xavier_uniform_
+        self.fc_mean = init(nn.Linear(num_inputs, num_outputs), init_method, lambda b: nn.init.constant_(b, 0), gain)
+        self.logstd = AddBias(torch.zeros(num_outputs))
+
+    def forward(self, x):
+        mean = self.fc_mean(x)
+        logstd = self.logstd(torch.zeros_like(mean))
+        return FixedNormal(mean, logstd.exp())
+
+
+LOG_SQRT_2PI = 0.5 * math.log(2 * math.pi)

@@ -1,0 +1,48 @@
+"""MLP trunk of actor and critic: LayerNorm(in) -> [Linear -> ReLU -> LayerNorm] x (1 + layer_N).
+
+Reference: uav_dcc_control/algos/algo_utils/mlp.py:7-58.  Parameter names (`feature_norm`, `mlp.fc1`,
+`mlp.fc2.<i>`) match the reference so that its state_dicts load; the reference's registered-but-
+never-run `fc_h` template (mlp.py:21-23, 66,304 dead parameters per network) is not
+created -- it would have `None` gradients and only complicate the gradient all-reduce.
+"""
+import torch.nn as nn
+
+from .util import init
+
+
+def _block(in_dim, hidden, use_orthogonal, use_relu):
+    act = nn.ReLU() if use_relu else nn.Tanh()
+    init_method = nn.init.orthogonal_ if use_orthogonal else nn.init.xavier_uniform_
+    gain = nn.init.calculate_gain("relu" if use_relu else "tanh")
+    lin = init(nn.Linear(in_dim, hidden), init_method, lambda b: nn.init.constant_(b, 0), gain=gain)
+    return nn.Sequential(lin, act, nn.LayerNorm(hidden))
+
+
+class MLPLayer(nn.Module):
+    def __init__(self, input_dim, hidden_size, layer_N, use_orthogonal, use_ReLU):
+        super().__init__()
+        self._layer_N = layer_N
+        self.fc1 = _block(input_dim, hidden_size, use_orthogonal, use_ReLU)
+        self.fc2 = nn.ModuleList([_block(hidden_size, hidden_size, use_orthogonal, use_ReLU) for _ in range(layer_N)])
+
+    def forward(self, x):
+        x = self.fc1(x)
+        for blk in self.fc2:
+            x = blk(x)
+        return x
+
+
+class MLPBase(nn.Module):
+    def __init__(self, cfg, obs_shape):
+        super().__init__()
+        self._use_feature_normalization = cfg.use_feature_normalization
+        self.hidden_size = cfg.algo_hidden_size
+        obs_dim = obs_shape[0]
+        if self._use_feature_normalization:
+            self.feature_norm = nn.LayerNorm(obs_dim)
+        self.mlp = MLPLayer(obs_dim, self.hidden_size, cfg.layer_N, cfg.use_orthogonal, cfg.use_ReLU)
+
+    def forward(self, x):
+        if self._use_feature_normalization:
+            x = self.feature_norm(x)
+        return self.mlp(x)

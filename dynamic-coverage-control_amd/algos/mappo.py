@@ -1,0 +1,264 @@
+"""MAPPO policy and trainer (reference: uav_dcc_control/algos/mappo.py:15-247), device-resident.
+
+What is kept from the reference (same entry points, same numerics, its quirks behind flags that
+default to the reference behaviour):
+  * MAPPOPolicy.get_actions / get_values / evaluate_actions / act / lr_decay        (mappo.py:39-65)
+  * MAPPOTrainer.cal_value_loss / ppo_update / train / prep_* / save_model / load_model
+  * PPO-clip surrogate summed over the action-log-prob columns: the reference stores the [B,1]
+    log-prob broadcast into an [.,2] buffer, so the surrogate is DOUBLED  ->
+    `double_surrogate=True`;  one-sided Huber (Q5);  ValueNorm.update inside every ppo_update (Q11).
+What is MI355X-first:
+  * every tensor of the update already lives on the GPU (no per-epoch host gather of B x (D+S));
+  * the centralised critic input is identical for the N agents of an env (learner.py:269-271), so
+    with `dedup_critic` it is evaluated once per env and broadcast (N x fewer critic FLOPs);
+  * one process per GPU: gradients are summed over ranks with one flat RCCL all-reduce per network
+    BEFORE clipping (so the clip sees the global gradient); advantage statistics and ValueNorm
+    moments are all-reduced too, which makes G ranks on E/G envs each equivalent to one rank on E.
+"""
+import os
+import pickle
+
+import torch
+import torch.nn as nn
+
+import utils.pytorch_utils as ptu
+from algos.r_actor_critic import R_Actor, R_Critic
+from utils.util import get_gard_norm, huber_loss, mse_loss, update_linear_schedule
+from utils.valuenorm import ValueNorm
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+
+class MAPPOPolicy:
+    def __init__(self, cfg, obs_space, cent_obs_space, act_space):
+        self.device = ptu.device
+        self.actor_lr, self.critic_lr = cfg.actor_lr, cfg.critic_lr
+        self.opti_eps, self.weight_decay = cfg.opti_eps, cfg.weight_decay
+        self.obs_space, self.share_obs_space, self.act_space = obs_space, cent_obs_space, act_space
+        self.actor = R_Actor(cfg, obs_space, act_space, ptu.device)
+        self.critic = R_Critic(cfg, cent_obs_space, ptu.device)
+        self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=self.actor_lr, eps=self.opti_eps,
+                                                weight_decay=self.weight_decay)
+        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=self.critic_lr, eps=self.opti_eps,
+                                                 weight_decay=self.weight_decay)
+
+    def broadcast_parameters(self, src=0):
+        """Replicas start identical: rank `src`'s parameters are broadcast once (no-op single process)."""
+        dist = _dist()
+        if dist is None:
+            return
+        for p in list(self.actor.parameters()) + list(self.critic.parameters()):
+            dist.broadcast(p.data, src)
+
+    def lr_decay(self, episode, episodes):
+        update_linear_schedule(self.actor_optimizer, episode, episodes, self.actor_lr)
+        update_linear_schedule(self.critic_optimizer, episode, episodes, self.critic_lr)
+
+    def get_actions(self, cent_obs, obs, rnn_states_actor=None, rnn_states_critic=None, masks=None,
+                    available_actions=None, deterministic=False):
+        actions, logp, rnn_states_actor = self.actor(obs, rnn_states_actor, masks, available_actions, deterministic)
+        values, rnn_states_critic = self.critic(cent_obs, rnn_states_critic, masks)
+        return values, actions, logp, rnn_states_actor, rnn_states_critic
+
+    def get_values(self, cent_obs, rnn_states_critic=None, masks=None):
+        return self.critic(cent_obs, rnn_states_critic, masks)[0]
+
+    def evaluate_actions(self, cent_obs, obs, rnn_states_actor, rnn_states_critic, action, masks,
+                         available_actions=None, active_masks=None):
+        logp, ent = self.actor.evaluate_actions(obs, rnn_states_actor, action, masks, available_actions, active_masks)
+        values, _ = self.critic(cent_obs, rnn_states_critic, masks)
+        return values, logp, ent
+
+    def act(self, obs, rnn_states_actor=None, masks=None, available_actions=None, deterministic=False):
+        actions, _, rnn_states_actor = self.actor(obs, rnn_states_actor, masks, available_actions, deterministic)
+        return actions, rnn_states_actor
+
+    def state_dict(self):
+        return {"actor": self.actor.state_dict(), "critic": self.critic.state_dict(),
+                "actor_optimizer": self.actor_optimizer.state_dict(),
+                "critic_optimizer": self.critic_optimizer.state_dict()}
+
+    def load_state_dict(self, sd):
+        self.actor.load_state_dict(sd["actor"]); self.critic.load_state_dict(sd["critic"])
+        if "actor_optimizer" in sd:
+            self.actor_optimizer.load_state_dict(sd["actor_optimizer"])
+            self.critic_optimizer.load_state_dict(sd["critic_optimizer"])
+
+
+def _allreduce_grads(params):
+    """Sum gradients over ranks with ONE flat all-reduce, then divide by the world size (each rank's
+    loss is a mean over its own equally sized batch shard, so the mean of means is the global mean)."""
+    dist = _dist()
+    if dist is None:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    flat /= dist.get_world_size()
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+class MAPPOTrainer:
+    def __init__(self, cfg, policy, agent_id=0):
+        self.tpdv = dict(dtype=torch.float32, device=ptu.device)
+        self.policy = policy
+        self.clip_param, self.ppo_epoch = cfg.clip_param, cfg.ppo_epoch
+        self.num_mini_batch = cfg.num_mini_batch
+        self.value_loss_coef, self.entropy_coef = cfg.value_loss_coef, cfg.entropy_coef
+        self.max_grad_norm, self.huber_delta = cfg.max_grad_norm, cfg.huber_delta
+        self._use_max_grad_norm = cfg.use_max_grad_norm
+        self._use_clipped_value_loss = cfg.use_clipped_value_loss
+        self._use_huber_loss = cfg.use_huber_loss
+        self._use_valuenorm = cfg.use_valuenorm
+        self._use_value_active_masks = cfg.use_value_active_masks
+        self._use_policy_active_masks = cfg.use_policy_active_masks
+        if cfg.use_popart:
+            raise NotImplementedError("PopArt is disabled in the reference config and not built")
+        if cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy:
+            raise NotImplementedError("recurrent generators are disabled in the reference config and not built")
+        # reference quirk Q4 (doubled surrogate) on by default; critic de-duplication is exact
+        self.double_surrogate = bool(getattr(cfg, "double_surrogate", True))
+        self.dedup_critic = bool(getattr(cfg, "dedup_critic", True))
+        self.value_normalizer = ValueNorm(1, device=ptu.device) if self._use_valuenorm else None
+
+    # ---- losses ---------------------------------------------------------------------------------
+    def cal_value_loss(self, values, value_preds_batch, return_batch, active_masks_batch):
+        """mappo.py:103-131 (ValueNorm.update happens here, once per ppo_update -- Q11)."""
+        value_pred_clipped = value_preds_batch + (values - value_preds_batch).clamp(-self.clip_param, self.clip_param)
+        if self._use_valuenorm:
+            self.value_normalizer.update(return_batch)
+            target = self.value_normalizer.normalize(return_batch)
+        else:
+            target = return_batch
+        error_clipped = target - value_pred_clipped
+        error_original = target - values
+        if self._use_huber_loss:
+            loss_clipped = huber_loss(error_clipped, self.huber_delta)
+            loss_original = huber_loss(error_original, self.huber_delta)
+        else:
+            loss_clipped, loss_original = mse_loss(error_clipped), mse_loss(error_original)
+        value_loss = torch.max(loss_original, loss_clipped) if self._use_clipped_value_loss else loss_original
+        if self._use_value_active_masks:
+            return (value_loss * active_masks_batch).sum() / active_masks_batch.sum()
+        return value_loss.mean()
+
+    def ppo_update(self, sample, update_actor=True):
+        """One full-batch PPO step (mappo.py:133-187).  `sample` is the 12-tuple of the reference's
+        feed_forward_generator; tensors may be numpy (drop-in) or device tensors (native path).
+        If `share_obs_batch` has fewer rows than `obs_batch` it holds ONE row per (step, env) and the
+        values are broadcast over the agents (dedup_critic)."""
+        (share_obs_batch, obs_batch, rnn_states_batch, rnn_states_critic_batch, actions_batch, value_preds_batch,
+         return_batch, masks_batch, active_masks_batch, old_action_log_probs_batch, adv_targ,
+         available_actions_batch) = sample
+        t = lambda x: ptu.to_tensor(x) if x is not None else None
+        old_logp, adv_targ = t(old_action_log_probs_batch), t(adv_targ)
+        value_preds_batch, return_batch, active_masks_batch = t(value_preds_batch), t(return_batch), t(active_masks_batch)
+        obs_batch, share_obs_batch, actions_batch = t(obs_batch), t(share_obs_batch), t(actions_batch)
+
+        action_log_probs, dist_entropy = self.policy.actor.evaluate_actions(
+            obs_batch, rnn_states_batch, actions_batch, masks_batch, available_actions_batch, active_masks_batch)
+        values = self.policy.critic(share_obs_batch)[0]
+        if values.shape[0] != obs_batch.shape[0]:
+            n_rep = obs_batch.shape[0] // values.shape[0]
+            values = values.unsqueeze(1).expand(-1, n_rep, -1).reshape(-1, 1)
+
+        imp_weights = torch.exp(action_log_probs - old_logp)   # [B, A] when old_logp keeps the reference's [.,2] layout
+        surr1 = imp_weights * adv_targ
+        surr2 = torch.clamp(imp_weights, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_targ
+        surr = torch.sum(torch.min(surr1, surr2), dim=-1, keepdim=True)
+        if self._use_policy_active_masks:
+            policy_loss = (-surr * active_masks_batch).sum() / active_masks_batch.sum()
+        else:
+            policy_loss = -surr.mean()
+        value_loss = self.cal_value_loss(values, value_preds_batch, return_batch, active_masks_batch)
+        if update_actor:
+            total_loss = (policy_loss - dist_entropy * self.entropy_coef) + value_loss * self.value_loss_coef
+        else:
+            total_loss = value_loss * self.value_loss_coef
+
+        self.policy.actor_optimizer.zero_grad(set_to_none=False)
+        self.policy.critic_optimizer.zero_grad(set_to_none=False)
+        total_loss.backward()
+        actor_params = list(self.policy.actor.parameters())
+        critic_params = list(self.policy.critic.parameters())
+        _allreduce_grads(actor_params)
+        _allreduce_grads(critic_params)
+        if self._use_max_grad_norm:
+            actor_grad_norm = nn.utils.clip_grad_norm_(actor_params, self.max_grad_norm)
+            critic_grad_norm = nn.utils.clip_grad_norm_(critic_params, self.max_grad_norm)
+        else:
+            actor_grad_norm, critic_grad_norm = get_gard_norm(actor_params), get_gard_norm(critic_params)
+        self.policy.actor_optimizer.step()
+        self.policy.critic_optimizer.step()
+        return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights
+
+    # ---- one training phase -------------------------------------------------------------------------
+    def normalized_advantages(self, buffer):
+        """mappo.py:190-198: adv = returns - denorm(V); (adv - mean) / (std + 1e-5) over active entries
+        (population std, like np.nanstd).  Moments are all-reduced over ranks."""
+        if self._use_valuenorm:
+            adv = buffer.returns[:-1] - self.value_normalizer.denormalize(buffer.value_preds[:-1])
+        else:
+            adv = buffer.returns[:-1] - buffer.value_preds[:-1]
+        act = buffer.active_masks[:-1]
+        w = (act != 0).to(adv.dtype)
+        stats = torch.stack([(adv * w).sum().double(), (adv.double() ** 2 * w).sum(), w.sum().double()])
+        dist = _dist()
+        if dist is not None:
+            dist.all_reduce(stats)
+        mean = stats[0] / stats[2]
+        var = (stats[1] / stats[2] - mean ** 2).clamp(min=0.0)
+        return ((adv - mean.float()) / (torch.sqrt(var).float() + 1e-5))
+
+    def train(self, buffer, update_actor=True):
+        """mappo.py:189-227: ppo_epoch passes, each over num_mini_batch mini-batches (1 = whole batch)."""
+        advantages = self.normalized_advantages(buffer)
+        info = {"value_loss": 0.0, "policy_loss": 0.0, "dist_entropy": 0.0, "actor_grad_norm": 0.0,
+                "critic_grad_norm": 0.0, "ratio": 0.0}
+        acc = torch.zeros(6, dtype=torch.float64, device=ptu.device)
+        for _ in range(self.ppo_epoch):
+            for sample in buffer.feed_forward_generator(advantages, self.num_mini_batch,
+                                                        dedup_critic=self.dedup_critic):
+                vl, cgn, pl, ent, agn, imp = self.ppo_update(sample, update_actor)
+                acc += torch.stack([vl.detach().double(), pl.detach().double(), ent.detach().double(),
+                                    torch.as_tensor(agn, device=acc.device).double(),
+                                    torch.as_tensor(cgn, device=acc.device).double(), imp.detach().mean().double()])
+        acc /= (self.ppo_epoch * self.num_mini_batch)
+        vals = acc.tolist()   # the only host sync of the update
+        for k, v in zip(("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"), vals):
+            info[k] = v
+        return info
+
+    def prep_training(self):
+        self.policy.actor.train(); self.policy.critic.train()
+
+    def prep_rollout(self):
+        self.policy.actor.eval(); self.policy.critic.eval()
+
+    # ---- checkpoints ----------------------------------------------------------------------------------
+    def save_model(self, save_path):
+        """Same location/name as the reference (mappo.py:237-240: <save_path>/agent.pkl).  The file is a
+        pickled dict of state_dicts (+ ValueNorm, which the reference's pickle of the policy object omits)."""
+        os.makedirs(save_path, exist_ok=True)
+        sd = self.policy.state_dict()
+        sd = {k: ({kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} if k in ("actor", "critic") else v)
+              for k, v in sd.items()}
+        if self.value_normalizer is not None:
+            sd["value_normalizer"] = {k: v.cpu() for k, v in self.value_normalizer.state_dict().items()}
+        with open(os.path.join(save_path, "agent.pkl"), "wb") as f:
+            pickle.dump(sd, f)
+
+    def load_model(self, load_path):
+        with open(os.path.join(load_path, "agent.pkl"), "rb") as f:
+            sd = pickle.load(f)
+        self.policy.load_state_dict(sd)
+        if self.value_normalizer is not None and "value_normalizer" in sd:
+            self.value_normalizer.load_state_dict(sd["value_normalizer"])
+        self.policy.actor.to(ptu.device); self.policy.critic.to(ptu.device)

@@ -1,0 +1,70 @@
+"""Actor and centralised critic of MAPPO (reference: uav_dcc_control/algos/r_actor_critic.py:19-121).
+
+Both are MLPBase trunks (LayerNorm -> Linear/ReLU/LayerNorm x2) on PyTorch-ROCm: the three GEMMs
+per network are the only dense contractions of the whole hot path and run on MFMA through
+hipBLASLt.  Inputs are expected to live on the device already (the rollout never leaves the GPU);
+numpy inputs are still accepted for drop-in use.  The recurrent / CNN / PopArt variants of the
+reference are disabled by its shipped config (mappo.yaml:21,28-29) and are not built; the cfg keys
+are accepted and must be off.
+"""
+import torch
+import torch.nn as nn
+
+from algos.algo_utils.act import ACTLayer
+from algos.algo_utils.mlp import MLPBase
+from algos.algo_utils.util import check, init
+from utils.util import get_shape_from_obs_space
+
+
+def _require_mlp(cfg, shape):
+    if len(shape) != 1:
+        raise NotImplementedError("only flat observations are on the coverage hot path")
+    if cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy:
+        raise NotImplementedError("recurrent policies are disabled in the reference config and not built")
+
+
+class R_Actor(nn.Module):
+    def __init__(self, cfg, obs_space, action_space, device=torch.device("cpu")):
+        super().__init__()
+        self.hidden_size = cfg.algo_hidden_size
+        self._use_policy_active_masks = cfg.use_policy_active_masks
+        self.tpdv = dict(dtype=torch.float32, device=device)
+        obs_shape = get_shape_from_obs_space(obs_space)
+        _require_mlp(cfg, obs_shape)
+        self.base = MLPBase(cfg, obs_shape)
+        self.act = ACTLayer(action_space, self.hidden_size, cfg.use_orthogonal, cfg.gain)
+        self.to(device)
+
+    def forward(self, obs, rnn_states=None, masks=None, available_actions=None, deterministic=False):
+        obs = check(obs).to(**self.tpdv)
+        feats = self.base(obs)
+        actions, logp = self.act(feats, available_actions, deterministic)
+        return actions, logp, rnn_states
+
+    def evaluate_actions(self, obs, rnn_states, action, masks, available_actions=None, active_masks=None):
+        obs = check(obs).to(**self.tpdv)
+        action = check(action).to(**self.tpdv)
+        if active_masks is not None:
+            active_masks = check(active_masks).to(**self.tpdv)
+        feats = self.base(obs)
+        return self.act.evaluate_actions(feats, action, available_actions,
+                                         active_masks=active_masks if self._use_policy_active_masks else None)
+
+
+class R_Critic(nn.Module):
+    def __init__(self, cfg, cent_obs_space, device=torch.device("cpu")):
+        super().__init__()
+        self.hidden_size = cfg.algo_hidden_size
+        if cfg.use_popart:
+            raise NotImplementedError("PopArt is disabled in the reference config and not built")
+        self.tpdv = dict(dtype=torch.float32, device=device)
+        shape = get_shape_from_obs_space(cent_obs_space)
+        _require_mlp(cfg, shape)
+        self.base = MLPBase(cfg, shape)
+        init_method = nn.init.orthogonal_ if cfg.use_orthogonal else nn.init.xavier_uniform_
+        self.v_out = init(nn.Linear(self.hidden_size, 1), init_method, lambda b: nn.init.constant_(b, 0))
+        self.to(device)
+
+    def forward(self, cent_obs, rnn_states=None, masks=None):
+        cent_obs = check(cent_obs).to(**self.tpdv)
+        return self.v_out(self.base(cent_obs)), rnn_states

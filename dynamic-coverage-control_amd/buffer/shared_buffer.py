@@ -1,0 +1,146 @@
+"""Rollout storage of MAPPO, resident on the GPU.
+
+Reference: uav_dcc_control/buffer/shared_buffer.py:14-279 (numpy arrays [T+1, E, N, ...], `insert`,
+`after_update`, `compute_returns` with GAE, `feed_forward_generator`).  Same attribute names and
+shapes, but:
+  * every array is a torch tensor on `ptu.device`; the env kernel writes observations straight into
+    `obs[t+1]` (no host copy, no pickling);
+  * `share_obs` is a VIEW: the centralised observation of an env is the concatenation of its agents'
+    observations (learner.py:217-220,269-271), i.e. `obs.view(T+1, E, N*D)`.  The reference repeats
+    it N times ([T+1,E,N,N*D], 53.5 GB at config 3); here it costs no memory and `share_obs[t]`
+    is an expanded view with the reference's [E, N, N*D] shape;
+  * `compute_returns` is one launch of the HIP GAE scan (include/dcc_gae.h) -- there is no CPU path;
+  * `feed_forward_generator` yields device tensors; with one mini-batch (the shipped setting) it
+    yields the whole batch without the randperm gather (the losses are means, order-free).
+"""
+import torch
+
+import utils.pytorch_utils as ptu
+from utils.util import get_shape_from_act_space, get_shape_from_obs_space
+
+
+class SharedReplayBuffer(object):
+    def __init__(self, cfg, obs_space, cent_obs_space, act_space, device=None):
+        self.device = device if device is not None else ptu.device
+        self.episode_length = cfg.max_ep_len
+        self.n_rollout_threads = cfg.n_rollout_threads
+        self.num_agents = cfg.num_agents
+        self.gamma, self.gae_lambda = cfg.gamma, cfg.gae_lambda
+        self._use_gae, self._use_valuenorm = cfg.use_gae, cfg.use_valuenorm
+        if cfg.use_popart or cfg.use_proper_time_limits or not cfg.use_gae:
+            raise NotImplementedError("only the reference's live branch (GAE, no PopArt, no proper time limits) is built")
+        T, E, N = self.episode_length, self.n_rollout_threads, self.num_agents
+        D = get_shape_from_obs_space(obs_space)[0]
+        S = get_shape_from_obs_space(cent_obs_space)[0]
+        A = get_shape_from_act_space(act_space)
+        self.obs_dim, self.share_obs_dim, self.act_dim = D, S, A
+        self._shared_is_view = (S == N * D)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
+        self.obs = z(T + 1, E, N, D)
+        self._share_obs = None if self._shared_is_view else z(T + 1, E, S)
+        self.value_preds = z(T + 1, E, N, 1)
+        self.returns = z(T + 1, E, N, 1)
+        self.advantages_raw = z(T, E, N, 1)
+        self.actions = z(T, E, N, A)
+        # the reference allocates [.., act_shape] for the log-probs and broadcasts the [.,1] value into
+        # it (shared_buffer.py:61-62,94); kept because the PPO surrogate sums over that axis (Q4)
+        self.action_log_probs = z(T, E, N, A)
+        self.rewards = z(T, E, N, 1)
+        self.masks = torch.ones(T + 1, E, N, 1, dtype=torch.float32, device=self.device)
+        self.bad_masks = torch.ones_like(self.masks)
+        self.active_masks = torch.ones_like(self.masks)
+        # recurrent policies are not built: zero-width placeholders keep `buffer.rnn_states[t]` indexable
+        self.rnn_states = z(T + 1, E, N, cfg.recurrent_N, 0)
+        self.rnn_states_critic = z(T + 1, E, N, cfg.recurrent_N, 0)
+        self.available_actions = None
+        self.step = 0
+
+    # ---- centralised observation -------------------------------------------------------------------
+    @property
+    def share_obs_env(self):
+        """[T+1, E, S]: one centralised observation per env (what the critic is fed with dedup_critic)."""
+        if self._shared_is_view:
+            T1, E, N, D = self.obs.shape
+            return self.obs.view(T1, E, N * D)
+        return self._share_obs
+
+    @property
+    def share_obs(self):
+        """[T+1, E, N, S] expanded view with the reference's shape (no memory)."""
+        so = self.share_obs_env
+        return so.unsqueeze(2).expand(-1, -1, self.num_agents, -1)
+
+    # ---- writing -----------------------------------------------------------------------------------------
+    def _t(self, x):
+        return ptu.to_tensor(x) if not (torch.is_tensor(x) and x.device == self.device and x.dtype == torch.float32) else x
+
+    def insert(self, share_obs, obs, rnn_states_actor, rnn_states_critic, actions, action_log_probs, value_preds,
+               rewards, masks, bad_masks=None, active_masks=None, available_actions=None):
+        """shared_buffer.py:72-105.  `obs` may be None when the env kernel already wrote obs[step+1]."""
+        s = self.step
+        if obs is not None:
+            self.obs[s + 1].copy_(self._t(obs).view_as(self.obs[s + 1]))
+        if share_obs is not None and not self._shared_is_view:
+            so = self._t(share_obs)
+            self._share_obs[s + 1].copy_(so[:, 0] if so.dim() == 3 else so)
+        self.actions[s].copy_(self._t(actions).view_as(self.actions[s]))
+        self.action_log_probs[s].copy_(self._t(action_log_probs).view(self.n_rollout_threads, self.num_agents, -1)
+                                       .expand_as(self.action_log_probs[s]))
+        self.value_preds[s].copy_(self._t(value_preds).view(self.n_rollout_threads, -1, 1).expand_as(self.value_preds[s]))
+        self.rewards[s].copy_(self._t(rewards).view(self.n_rollout_threads, -1, 1).expand_as(self.rewards[s]))
+        self.masks[s + 1].copy_(self._t(masks).view(self.n_rollout_threads, -1, 1).expand_as(self.masks[s + 1]))
+        if bad_masks is not None:
+            self.bad_masks[s + 1].copy_(self._t(bad_masks))
+        if active_masks is not None:
+            self.active_masks[s + 1].copy_(self._t(active_masks))
+        self.step = (self.step + 1) % self.episode_length
+
+    def after_update(self):
+        """shared_buffer.py:142-152: the last slot becomes slot 0."""
+        self.obs[0].copy_(self.obs[-1])
+        if not self._shared_is_view:
+            self._share_obs[0].copy_(self._share_obs[-1])
+        self.masks[0].copy_(self.masks[-1])
+        self.bad_masks[0].copy_(self.bad_masks[-1])
+        self.active_masks[0].copy_(self.active_masks[-1])
+
+    # ---- returns --------------------------------------------------------------------------------------------
+    def compute_returns(self, next_value, value_normalizer=None):
+        """GAE(gamma, lambda) on denormalised values, reverse scan segmented by `masks`
+        (shared_buffer.py:199-208) -- one launch of dcc_gae_compute.  Also fills `advantages_raw`
+        = returns - denorm(value_preds) (mappo.py:191)."""
+        import dcc_hip
+        T, E, N = self.episode_length, self.n_rollout_threads, self.num_agents
+        nv = self._t(next_value)
+        self.value_preds[-1].copy_(nv.view(E, -1, 1).expand_as(self.value_preds[-1]))
+        denorm = value_normalizer.denorm_params() if (value_normalizer is not None and self._use_valuenorm) else None
+        dcc_hip.gae_compute(self.rewards.view(T, E * N), self.value_preds.view(T + 1, E * N),
+                            self.masks.view(T + 1, E * N), denorm, self.gamma, self.gae_lambda,
+                            self.returns.view(T + 1, E * N), self.advantages_raw.view(T, E * N))
+
+    # ---- sampling -----------------------------------------------------------------------------------------------
+    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None, dedup_critic=False):
+        """shared_buffer.py:219-279.  Yields the reference's 12-tuple of [B, .] tensors (device).
+        dedup_critic: `share_obs_batch` carries ONE row per (step, env) -- mini-batches are then drawn
+        over (step, env) pairs and contain all N agents of each pair."""
+        T, E, N = self.episode_length, self.n_rollout_threads, self.num_agents
+        num_mini_batch = num_mini_batch or 1
+        rows = lambda x: x.reshape(T * E * N, -1)
+        adv = torch.as_tensor(advantages).to(self.device, torch.float32)
+        if num_mini_batch == 1 and mini_batch_size is None:
+            so = self.share_obs_env[:-1].reshape(T * E, -1) if dedup_critic else self.share_obs[:-1].reshape(T * E * N, -1)
+            yield (so, rows(self.obs[:-1]), None, None, rows(self.actions), rows(self.value_preds[:-1]),
+                   rows(self.returns[:-1]), rows(self.masks[:-1]), rows(self.active_masks[:-1]),
+                   rows(self.action_log_probs), rows(adv), None)
+            return
+        pairs = T * E
+        per = mini_batch_size // N if mini_batch_size else pairs // num_mini_batch
+        perm = torch.randperm(pairs, device=self.device)
+        pr = lambda x: x.reshape(pairs, N, -1)
+        for i in range(num_mini_batch):
+            idx = perm[i * per:(i + 1) * per]
+            g = lambda x: pr(x)[idx].reshape(idx.numel() * N, -1)
+            so_env = self.share_obs_env[:-1].reshape(pairs, -1)[idx]
+            so = so_env if dedup_critic else so_env.unsqueeze(1).expand(-1, N, -1).reshape(idx.numel() * N, -1)
+            yield (so, g(self.obs[:-1]), None, None, g(self.actions), g(self.value_preds[:-1]), g(self.returns[:-1]),
+                   g(self.masks[:-1]), g(self.active_masks[:-1]), g(self.action_log_probs), g(adv), None)

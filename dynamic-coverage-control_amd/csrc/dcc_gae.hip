@@ -1,0 +1,78 @@
+// dcc_gae.hip -- GAE(gamma, lambda) returns as a backwards, mask-segmented scan on the device.
+//
+// One lane per (env, agent) column; columns are contiguous in memory ([T, E, N] row-major), so
+// every load/store of a wavefront is one coalesced 256-byte transaction.  The recurrence runs in
+// float32 in the reference's exact operation order (buffer/shared_buffer.py:199-208 with the
+// torch float32 `v * sqrt(var) + mean` of utils/valuenorm.py:75 folded in), compiled with
+// -ffp-contract=off, so the result is bit-identical to the reference's numpy loop.  The loads of
+// step t-1 do not depend on the recurrence, so they are issued ahead of it (software prefetch).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "dcc_gae.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void dcc_gae_kernel(const float* __restrict__ rewards,
+                                                      const float* __restrict__ vpred,
+                                                      const float* __restrict__ masks,
+                                                      const float* __restrict__ denorm, float gamma, float gl,
+                                                      float* __restrict__ returns, float* __restrict__ adv, int T,
+                                                      long long C) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean = 0.f, sd = 1.f;
+    const bool dn = denorm != nullptr;
+    if (dn) { mean = denorm[0]; sd = denorm[1]; }
+    // denormalised V(s_{t+1}) carried across iterations
+    float v_next = vpred[(long long)T * C + c];
+    if (dn) v_next = v_next * sd + mean;
+    float gae = 0.f;
+    // prefetch step T-1
+    float r = rewards[(long long)(T - 1) * C + c];
+    float v = vpred[(long long)(T - 1) * C + c];
+    float m = masks[(long long)T * C + c];
+    for (int t = T - 1; t >= 0; --t) {
+        float r_p = 0.f, v_p = 0.f, m_p = 0.f;
+        if (t > 0) {
+            r_p = rewards[(long long)(t - 1) * C + c];
+            v_p = vpred[(long long)(t - 1) * C + c];
+            m_p = masks[(long long)t * C + c];
+        }
+        const float v_cur = dn ? (v * sd + mean) : v;
+        // delta = r[t] + gamma * V[t+1] * mask[t+1] - V[t]          (shared_buffer.py:203-205)
+        const float delta = (r + (gamma * v_next) * m) - v_cur;
+        // gae = delta + gamma*lambda * mask[t+1] * gae               (shared_buffer.py:206)
+        gae = delta + (gl * m) * gae;
+        const float ret = gae + v_cur;                              // shared_buffer.py:207
+        returns[(long long)t * C + c] = ret;
+        if (adv) adv[(long long)t * C + c] = ret - v_cur;           // mappo.py:191
+        v_next = v_cur;
+        r = r_p; v = v_p; m = m_p;
+    }
+}
+
+thread_local std::string g_gae_err;
+
+}  // namespace
+
+extern "C" {
+
+DCC_API int dcc_gae_compute(const float* rewards, const float* value_preds, const float* masks, const float* denorm,
+                            double gamma, double gae_lambda, float* returns, float* advantages, int32_t T, int64_t C,
+                            void* stream) {
+    if (!rewards || !value_preds || !masks || !returns || T < 1 || C < 1) return -1;
+    const int block = 256;
+    const long long grid = (C + block - 1) / block;
+    if (grid > 0x7fffffffLL) return -1;
+    // numpy turns the Python floats into float32 scalars: gamma -> f32(gamma), gamma*lambda (computed
+    // in float64 first, shared_buffer.py:206 evaluates left to right) -> f32
+    const float g = (float)gamma, gl = (float)(gamma * gae_lambda);
+    hipLaunchKernelGGL(dcc_gae_kernel, dim3((unsigned)grid), dim3(block), 0, reinterpret_cast<hipStream_t>(stream),
+                       rewards, value_preds, masks, denorm, g, gl, returns, advantages, (int)T, (long long)C);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // extern "C"

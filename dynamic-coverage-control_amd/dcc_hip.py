@@ -39,7 +39,7 @@ class EnvOut(ctypes.Structure):
                 ("coverage", _vp), ("assign", _vp), ("reward64", _vp)]
 
 
-EXPORTS = ["dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
+EXPORTS = ["dcc_gae_compute", "dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
            "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout", "dcc_env_get_state",
            "dcc_env_set_state", "dcc_env_bytes_per_step"]
 
@@ -71,6 +71,8 @@ def load_library(path=None):
     L.dcc_env_set_state.argtypes = [_vp] * 6
     L.dcc_env_bytes_per_step.argtypes = [ctypes.c_int32] * 4
     L.dcc_env_bytes_per_step.restype = ctypes.c_int64
+    L.dcc_gae_compute.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, ctypes.c_int32,
+                                  ctypes.c_int64, _vp]
     if L.dcc_abi_version() != 1:
         raise DccError("libdcc_hip.so ABI version %d != 1" % L.dcc_abi_version())
     _lib = L
@@ -229,3 +231,27 @@ class HipCoverageEnv:
             _check(self.lib.dcc_env_set_state(self._h, _ptr(pos), _ptr(vel), _ptr(energy), _ptr(done), _stream()),
                    "dcc_env_set_state")
             torch.cuda.current_stream().synchronize()  # inputs may be temporaries
+
+
+def gae_compute(rewards, value_preds, masks, denorm, gamma, gae_lambda, returns, advantages=None):
+    """include/dcc_gae.h: rewards [T,C], value_preds/masks/returns [T+1,C], denorm [2] or None, advantages [T,C]
+    or None -- contiguous float32 tensors on one HIP device.  No CPU path."""
+    L = load_library()
+    T, C = rewards.shape
+    ts = [("rewards", rewards, (T, C)), ("value_preds", value_preds, (T + 1, C)), ("masks", masks, (T + 1, C)),
+          ("returns", returns, (T + 1, C))]
+    if advantages is not None:
+        ts.append(("advantages", advantages, (T, C)))
+    if denorm is not None:
+        ts.append(("denorm", denorm, (2,)))
+    for name, t, shape in ts:
+        if not t.is_cuda:
+            raise DccError("gae_compute: %s is not on a HIP device (there is no CPU path)" % name)
+        if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shape or t.device != rewards.device:
+            raise ValueError("gae_compute: %s must be contiguous float32 %s on %s" % (name, shape, rewards.device))
+    with torch.cuda.device(rewards.device):
+        rc = L.dcc_gae_compute(_ptr(rewards), _ptr(value_preds), _ptr(masks), _ptr(denorm), float(gamma),
+                               float(gae_lambda), _ptr(returns), _ptr(advantages), T, C, _stream())
+    if rc != 0:
+        raise DccError("dcc_gae_compute failed (%d)" % rc)
+    return returns

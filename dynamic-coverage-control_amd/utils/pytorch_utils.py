@@ -1,0 +1,95 @@
+"""Device plumbing used by train.py / learner.py (`ptu.set_gpu_mode`, `ptu.device`, tensor helpers).
+
+Mirrors the names the reference's train.py and algos import (uav_dcc_control/utils/pytorch_utils.py:
+121-180) so that an unchanged train.py runs.  Differences, on purpose:
+  * `set_gpu_mode` does NOT export CUDA_VISIBLE_DEVICES (the reference sets it *and* uses
+    cuda:<id>, which is inconsistent for id > 0 -- SURVEY.md Q10); it selects the HIP device.
+  * one process per GPU: `init_distributed()` picks the device from LOCAL_RANK and brings up
+    torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU).
+"""
+import os
+
+import numpy as np
+import torch
+
+_use_gpu = False
+_gpu_id = 0
+device = torch.device("cpu")
+
+
+def set_gpu_mode(mode, gpu_id=0):
+    global _use_gpu, _gpu_id, device
+    _gpu_id = int(gpu_id)
+    _use_gpu = bool(mode)
+    device = torch.device("cuda:%d" % _gpu_id if _use_gpu else "cpu")
+    if _use_gpu:
+        torch.cuda.set_device(device)
+
+
+def gpu_enabled():
+    return _use_gpu
+
+
+def init_distributed(backend=None):
+    """One process per GPU.  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment
+    (torch.distributed.run); no-op when WORLD_SIZE is 1.  Returns (rank, world_size)."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world == 1:
+        return 0, 1
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        set_gpu_mode(True, int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def world_size():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def from_numpy(*args, **kwargs):
+    return torch.from_numpy(*args, **kwargs).float().to(device)
+
+
+def to_tensor(x, dtype=torch.float32):
+    """numpy / tensor -> tensor on `device` (no copy when it already lives there)."""
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(x)
+    return x.to(device=device, dtype=dtype)
+
+
+def get_numpy(tensor):
+    return tensor.detach().to("cpu").numpy()
+
+
+def zeros(*sizes, **kwargs):
+    return torch.zeros(*sizes, **kwargs, device=device)
+
+
+def ones(*sizes, **kwargs):
+    return torch.ones(*sizes, **kwargs, device=device)
+
+
+def eye(*sizes, **kwargs):
+    return torch.eye(*sizes, **kwargs, device=device)
+
+
+def randn(*args, **kwargs):
+    return torch.randn(*args, **kwargs, device=device)
+
+
+def zeros_like(*args, **kwargs):
+    return torch.zeros_like(*args, **kwargs).to(device)
+
+
+def ones_like(*args, **kwargs):
+    return torch.ones_like(*args, **kwargs).to(device)

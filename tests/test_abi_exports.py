@@ -28,7 +28,7 @@ def _libpath():
 def test_header_declares_expected_entry_points():
     d = _declared()
     for n in ("dcc_env_create", "dcc_env_step", "dcc_env_reset", "dcc_env_rollout", "dcc_env_destroy",
-              ):
+              "dcc_gae_compute"):
         assert n in d, n
 
 

@@ -1,0 +1,196 @@
+"""MAPPO numerics against fixtures produced by the reference's own algos.mappo / buffer.shared_buffer /
+utils.valuenorm (tools/gen_golden_mappo.py).  CPU torch: this is host-side PyTorch logic, the HIP
+GAE kernel is checked in test_gae_hip.py (-m gpu)."""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+Z = np.load(os.path.join(GOLDEN, "mappo_small.npz"))
+N, E, T, D, A, H = 4, 3, 16, 20, 2, 32
+S = N * D
+
+
+def make_cfg(**over):
+    c = dict(num_agents=N, n_rollout_threads=E, max_ep_len=T, algo_hidden_size=H, ppo_epoch=2, layer_N=1,
+             use_ReLU=True, use_popart=False, use_valuenorm=True, use_feature_normalization=True, use_orthogonal=True,
+             gain=0.01, use_recurrent_policy=False, use_naive_recurrent_policy=False, recurrent_N=1,
+             actor_lr=5e-4, critic_lr=5e-4, opti_eps=1e-5, weight_decay=0, use_clipped_value_loss=True,
+             clip_param=0.2, num_mini_batch=1, entropy_coef=0.01, value_loss_coef=1, use_max_grad_norm=True,
+             max_grad_norm=10.0, use_gae=True, gamma=0.99, gae_lambda=0.95, use_proper_time_limits=False,
+             use_huber_loss=True, use_value_active_masks=True, use_policy_active_masks=True, huber_delta=10.0,
+             data_chunk_length=10, stacked_frames=1)
+    c.update(over)
+    return Namespace(**c)
+
+
+class Box:
+    def __init__(self, n):
+        self.shape = (n,)
+
+
+def _sd(prefix):
+    return {k[len(prefix):]: torch.from_numpy(Z[k]) for k in Z.files if k.startswith(prefix)}
+
+
+def _policy(cfg):
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(False)
+    from algos.mappo import MAPPOPolicy, MAPPOTrainer
+    pol = MAPPOPolicy(cfg, Box(D), Box(S), Box(A))
+    # the reference's state_dict also holds its dead `mlp.fc_h` template: ignored
+    missing, unexpected = pol.actor.load_state_dict(_sd("actor/"), strict=False)
+    assert not missing and all(".fc_h." in k for k in unexpected)
+    missing, unexpected = pol.critic.load_state_dict(_sd("critic/"), strict=False)
+    assert not missing and all(".fc_h." in k for k in unexpected)
+    return pol, MAPPOTrainer(cfg, pol)
+
+
+def test_parameter_counts_match_reference_live_parameters():
+    pol, _ = _policy(make_cfg())
+    live = lambda pre: sum(Z[k].size for k in Z.files if k.startswith(pre) and ".fc_h." not in k)
+    assert sum(p.numel() for p in pol.actor.parameters()) == live("actor/")
+    assert sum(p.numel() for p in pol.critic.parameters()) == live("critic/")
+    # SURVEY.md 8e closed forms (H=256): actor 258*D + 67,588 ; critic 258*S + 67,329
+    h = 32
+    assert live("actor/") == (2 * D) + (D * h + h) + 2 * h + (h * h + h) + 2 * h + (h * A + A) + A
+
+
+def test_fresh_policy_entropy_is_2p8379():
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(False)
+    from algos.mappo import MAPPOPolicy
+    pol = MAPPOPolicy(make_cfg(), Box(D), Box(S), Box(A))
+    _, _, ent = pol.evaluate_actions(torch.zeros(5, S), torch.zeros(5, D), None, None, torch.zeros(5, A), None, None,
+                                     torch.ones(5, 1))
+    assert abs(float(ent) - 2.8379) < 1e-3     # 2 * (0.5 + 0.5 ln 2 pi), sigma = 1
+
+
+def test_evaluate_actions_matches_reference():
+    pol, tr = _policy(make_cfg())
+    tr.prep_rollout()
+    with torch.no_grad():
+        v, logp, ent = pol.evaluate_actions(Z["ev_sobs"], Z["ev_obs"], None, None, Z["ev_act"], None, None,
+                                            torch.ones(64, 1))
+        mean_act, _ = pol.act(Z["ev_obs"], deterministic=True)
+    np.testing.assert_allclose(v.numpy(), Z["ev_values"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(logp.numpy(), Z["ev_logp"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(ent), float(Z["ev_entropy"]), rtol=1e-6)
+    np.testing.assert_allclose(mean_act.numpy(), Z["ev_mean_act"], rtol=1e-5, atol=1e-7)
+
+
+def test_huber_is_one_sided_like_the_reference():
+    from utils.util import huber_loss
+    out = huber_loss(torch.from_numpy(Z["huber_e"]), 10.0).numpy()
+    np.testing.assert_array_equal(out, Z["huber_out"])
+    assert out[0] == 0.0          # e = -25 < -delta contributes nothing (Q5)
+
+
+def _set_vn(vn, pre):
+    vn.running_mean.copy_(torch.from_numpy(Z[pre + "_mean"]))
+    vn.running_mean_sq.copy_(torch.from_numpy(Z[pre + "_mean_sq"]))
+    vn.debiasing_term.copy_(torch.from_numpy(Z[pre + "_debias"]))
+
+
+def test_oracle_gae_matches_reference_bit_exact():
+    from oracle import mappo_oracle as mo
+    mean, std = mo.valuenorm_mean_std(Z["vn0_mean"][0], Z["vn0_mean_sq"][0], Z["vn0_debias"])
+    ret, vp = mo.compute_returns_gae(Z["buf_rewards"], Z["buf_value_preds"], Z["buf_masks"], Z["next_value"], 0.99,
+                                     0.95, mean, std)
+    np.testing.assert_array_equal(vp, Z["buf_value_preds_after"])
+    np.testing.assert_array_equal(ret, Z["returns"])
+
+
+def test_valuenorm_matches_reference():
+    from utils.valuenorm import ValueNorm
+    from oracle import mappo_oracle as mo
+    vn = ValueNorm(1)
+    rs = np.random.RandomState(11)   # replay the fixture's draws up to the ValueNorm updates
+    rs.normal(0, 1, (64, D)); rs.normal(0, 1, (64, S)); rs.uniform(-1, 1, (64, A))
+    rs.normal(0, 1, (T + 1, E, N, D)); rs.uniform(-1, 1, (T, E, N, A)); rs.normal(-2.5, 0.3, (T, E, N, 1))
+    rs.normal(-50, 30, (T, E, 1, 1)); rs.normal(0, 1, (T + 1, E, 1, 1))
+    vn.update(rs.normal(-300, 120, (200, 1)).astype(np.float32))
+    vn.update(rs.normal(-280, 100, (200, 1)).astype(np.float32))
+    np.testing.assert_allclose(vn.running_mean.numpy(), Z["vn0_mean"], rtol=1e-6)
+    np.testing.assert_allclose(vn.running_mean_sq.numpy(), Z["vn0_mean_sq"], rtol=1e-6)
+    np.testing.assert_allclose(vn.debiasing_term.numpy(), Z["vn0_debias"], rtol=1e-6)
+    _set_vn(vn, "vn0")
+    mean, std = mo.valuenorm_mean_std(Z["vn0_mean"][0], Z["vn0_mean_sq"][0], Z["vn0_debias"])
+    p = vn.denorm_params().numpy()
+    assert p[0] == mean and p[1] == std
+    x = torch.from_numpy(Z["buf_value_preds"])
+    np.testing.assert_array_equal(vn.denormalize(x).numpy(), Z["buf_value_preds"] * std + mean)
+
+
+def _filled_buffer(cfg):
+    from buffer.shared_buffer import SharedReplayBuffer
+    buf = SharedReplayBuffer(cfg, Box(D), Box(S), Box(A))
+    buf.obs.copy_(torch.from_numpy(Z["buf_obs"]))
+    buf.actions.copy_(torch.from_numpy(Z["buf_actions"]))
+    buf.action_log_probs.copy_(torch.from_numpy(Z["buf_logp"]))
+    buf.rewards.copy_(torch.from_numpy(Z["buf_rewards"]))
+    buf.value_preds.copy_(torch.from_numpy(Z["buf_value_preds_after"]))
+    buf.masks.copy_(torch.from_numpy(Z["buf_masks"]))
+    buf.returns.copy_(torch.from_numpy(Z["returns"]))   # the HIP GAE kernel is tested on the GPU
+    return buf
+
+
+def test_share_obs_is_a_view_with_reference_shape():
+    buf = _filled_buffer(make_cfg())
+    so = buf.share_obs
+    assert tuple(so.shape) == (T + 1, E, N, S)
+    ref = np.repeat(Z["buf_obs"].reshape(T + 1, E, 1, S), N, axis=2)
+    np.testing.assert_array_equal(so.numpy(), ref)
+    assert buf.share_obs_env.data_ptr() == buf.obs.data_ptr()      # no copy
+
+
+@pytest.mark.parametrize("dedup", [False, True])
+def test_train_matches_reference(dedup):
+    cfg = make_cfg(dedup_critic=dedup)
+    pol, tr = _policy(cfg)
+    _set_vn(tr.value_normalizer, "vn0")
+    buf = _filled_buffer(cfg)
+    adv = tr.normalized_advantages(buf)
+    np.testing.assert_allclose(adv.numpy(), Z["adv_norm"], rtol=2e-5, atol=2e-6)
+    tr.prep_training()
+    info = tr.train(buf, update_actor=True)
+    for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"):
+        np.testing.assert_allclose(info[k], float(Z["info_" + k]), rtol=2e-4, atol=1e-6, err_msg=k)
+    for pre, mod in (("actor2/", pol.actor), ("critic2/", pol.critic)):
+        for k, v in mod.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), Z[pre + k], rtol=1e-3, atol=2e-5, err_msg=pre + k)
+    np.testing.assert_allclose(tr.value_normalizer.running_mean.numpy(), Z["vn1_mean"], rtol=1e-5)
+    np.testing.assert_allclose(tr.value_normalizer.debiasing_term.numpy(), Z["vn1_debias"], rtol=1e-6)
+
+
+def test_surrogate_doubling_flag():
+    """Q4: with the reference's [.,2] log-prob layout the policy loss is exactly twice the [.,1] one."""
+    cfg = make_cfg()
+    pol, tr = _policy(cfg)
+    _set_vn(tr.value_normalizer, "vn0")
+    buf = _filled_buffer(cfg)
+    adv = tr.normalized_advantages(buf)
+    s = next(buf.feed_forward_generator(adv, 1))
+    tr.prep_training()
+    torch.manual_seed(0)
+    _, _, pl2, _, _, imp = tr.ppo_update(s)
+    assert imp.shape[-1] == 2
+    pol1, tr1 = _policy(cfg)
+    _set_vn(tr1.value_normalizer, "vn0")
+    s1 = list(s); s1[9] = s[9][:, :1].contiguous()
+    _, _, pl1, _, _, imp1 = tr1.ppo_update(tuple(s1))
+    assert imp1.shape[-1] == 1
+    np.testing.assert_allclose(float(pl2), 2 * float(pl1), rtol=1e-5)
+
+
+def test_buffer_gae_has_no_cpu_path():
+    import dcc_hip
+    cfg = make_cfg()
+    buf = _filled_buffer(cfg)
+    from utils.valuenorm import ValueNorm
+    with pytest.raises(dcc_hip.DccError):
+        buf.compute_returns(torch.zeros(E, N, 1), ValueNorm(1))
