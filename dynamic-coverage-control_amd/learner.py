@@ -1,0 +1,207 @@
+"""Learner: warmup -> [collect -> env.step -> insert] x T -> compute (GAE) -> rl_update, per iteration.
+
+Same entry point and method names as the reference orchestrator (uav_dcc_control/learner.py:21-321:
+`Learner(cfg).train()`, `rollout`, `warmup`, `collect`, `insert`, `compute`, `rl_update`, `log`,
+`save_model`, `load_model`), so the reference's train.py drives it unchanged.  The data path is
+different: nothing crosses the host between env step, policy forward, rollout storage, GAE and the
+PPO update --
+
+  obs[t] (device) --actor/critic GEMMs--> actions --HIP env kernel--> obs[t+1] written in place
+  rewards/dones/values --> buffer slots --HIP GAE scan--> returns --> 15 full-batch PPO epochs
+
+and in a multi-GPU job each rank owns n_rollout_threads / world_size envs, with one RCCL all-reduce
+of the gradients per ppo_update (algos/mappo.py).
+"""
+import copy
+import datetime
+import json
+import os
+import time
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+import utils.pytorch_utils as ptu
+from buffer.shared_buffer import SharedReplayBuffer
+from envs.make_env import make_env
+from utils import util as utl
+
+
+def _to_namespace(cfg):
+    if isinstance(cfg, Namespace):
+        return copy.deepcopy(cfg)
+    try:
+        from omegaconf import OmegaConf
+        if OmegaConf.is_config(cfg):
+            return Namespace(**OmegaConf.to_container(cfg, resolve=True))
+    except ImportError:
+        pass
+    return Namespace(**dict(cfg))
+
+
+class Learner:
+    def __init__(self, cfg):
+        self.cfg = _to_namespace(cfg)
+        for k, v in (("double_surrogate", True), ("dedup_critic", True)):
+            if not hasattr(self.cfg, k):
+                setattr(self.cfg, k, v)
+        self.rank, self.world = ptu.init_distributed() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
+        utl.seed(self.cfg.seed + self.rank)
+
+        # 1. env (global n_rollout_threads is sharded over ranks inside make_env)
+        self.train_envs = make_env(cfg=copy.deepcopy(self.cfg))
+        self.n_agents = self.cfg.num_agents
+        self.max_ep_len = self.cfg.max_ep_len
+        self.obs_dim_n = [self.train_envs.observation_space[i].shape[0] for i in range(self.n_agents)]
+        self.action_dim_n = [self.train_envs.action_space[i].shape[0] for i in range(self.n_agents)]
+        self.cfg.action_dim_n, self.cfg.obs_dim_n = self.action_dim_n, self.obs_dim_n
+        if self.rank == 0:
+            print("initial train envs: %s, done (%d envs on this GPU, %d GPUs)"
+                  % (self.cfg.save_name, self.train_envs.n_envs, self.world))
+
+        # 2. policy / trainer
+        self.use_centralized_V = self.cfg.use_centralized_V
+        if not self.use_centralized_V:
+            raise NotImplementedError("use_centralized_V: false is not on the reference's shipped path")
+        self.share_observation_space = self.train_envs.share_observation_space[0]
+        from algos.mappo import MAPPOPolicy, MAPPOTrainer
+        self.policy = MAPPOPolicy(self.cfg, self.train_envs.observation_space[0], self.share_observation_space,
+                                  self.train_envs.action_space[0])
+        self.policy.broadcast_parameters(0)
+        self.trainer = MAPPOTrainer(cfg=self.cfg, policy=self.policy)
+
+        # 3. buffers (sized for the LOCAL env shard)
+        self.rl_buffer = self._make_buffer(self.train_envs)
+        self.test_envs = self.test_buffer = None
+        if self.cfg.n_eval_rollout_threads > 0:
+            tcfg = copy.deepcopy(self.cfg)
+            tcfg.n_rollout_threads = max(self.world, self.cfg.n_eval_rollout_threads // self.world * self.world)
+            self.test_envs = make_env(tcfg)
+            self.test_buffer = self._make_buffer(self.test_envs)
+
+        # 4. loop parameters
+        self.use_linear_lr_decay = self.cfg.use_linear_lr_decay
+        self.n_iters = self.cfg.n_iters
+        self.eval_interval, self.log_interval = self.cfg.eval_interval, self.cfg.log_interval
+        self.is_save_model, self.save_interval = self.cfg.save_model, self.cfg.save_interval
+        if getattr(self.cfg, "load_model", False):
+            self.load_model(self.cfg.load_model_path)
+        self.expt_name = datetime.datetime.now().strftime("%m%d_%H%M_") + "sd{}".format(self.cfg.seed)
+        if self.is_save_model and self.rank == 0:
+            self.output_path = str(os.path.join(self.cfg.main_save_path, self.cfg.save_name, self.expt_name))
+            self.cfg.output_path = self.output_path
+            os.makedirs(self.output_path, exist_ok=True)
+            with open(os.path.join(self.output_path, "config.json"), "w") as f:
+                json.dump({k: v for k, v in vars(self.cfg).items()}, f, indent=4, default=str)
+        self._start_time = self._check_time = time.time()
+        self.total_env_steps = 0
+
+    def _make_buffer(self, envs):
+        bcfg = copy.deepcopy(self.cfg)
+        bcfg.n_rollout_threads = envs.n_envs
+        return SharedReplayBuffer(bcfg, envs.observation_space[0], envs.share_observation_space[0], envs.action_space[0])
+
+    # ---- training loop (learner.py:132-175) ---------------------------------------------------------
+    def train(self):
+        self.warmup(self.rl_buffer, self.train_envs)
+        for iter_ in range(1, self.n_iters + 1):
+            if self.use_linear_lr_decay:
+                self.trainer.policy.lr_decay(iter_, self.n_iters)
+            rollout_info = self.rollout(self.rl_buffer, self.train_envs)
+            rl_train_info = self.rl_update()
+            test_rollout_info = {}
+            if self.test_envs is not None and iter_ % self.eval_interval == 0:
+                test_rollout_info = self.rollout(self.test_buffer, self.test_envs)
+            if iter_ % self.log_interval == 0:
+                self.log(iter_=iter_, rollout_info=rollout_info, rl_train_info=rl_train_info,
+                         test_rollout_info=test_rollout_info)
+            if self.is_save_model and self.rank == 0 and iter_ % self.save_interval == 0:
+                save_path = os.path.join(self.output_path, "models_%d.pt" % iter_)
+                self.save_model(save_path)
+                print("model saved in %s" % save_path)
+        self.train_envs.close()
+        if self.test_envs is not None:
+            self.test_envs.close()
+
+    # ---- rollout (learner.py:178-214) -------------------------------------------------------------------
+    @torch.no_grad()
+    def rollout(self, r_buffer, r_envs, is_render=False, iter_=0):
+        self.warmup(r_buffer, r_envs)
+        rew_sum = torch.zeros((), dtype=torch.float64, device=ptu.device)
+        cov_max = torch.zeros(r_envs.n_envs, dtype=torch.float32, device=ptu.device)
+        for cur_step in range(self.max_ep_len):
+            values, actions, action_log_probs = self.collect(cur_step, r_buffer)
+            out = r_envs.step_device(actions, obs_out=r_buffer.obs[cur_step + 1])
+            self.insert((out, values, actions, action_log_probs), r_buffer)
+            rew_sum += out["reward"].double().mean()
+            cov_max = torch.maximum(cov_max, out["coverage"])
+        self.compute(r_buffer)
+        self.total_env_steps += self.max_ep_len * r_envs.n_envs * self.world
+        stats = torch.stack([rew_sum, cov_max.double().mean()])
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(stats)
+            stats /= self.world
+        r, c = stats.tolist()
+        return {"reward": r, "coverage_rate": c}
+
+    def warmup(self, r_buffer, r_envs):
+        """reset every env; obs -> slot 0 (learner.py:216-225; share_obs is a view of obs here)."""
+        r_envs.reset_device(r_buffer.obs[0])
+        r_buffer.masks[0].fill_(1.0)
+        r_buffer.step = 0
+
+    @torch.no_grad()
+    def collect(self, cur_step, r_buffer):
+        """policy forward on the E*N agent rows, critic on the E env rows (learner.py:227-252)."""
+        self.trainer.prep_rollout()
+        E, N = r_buffer.n_rollout_threads, self.n_agents
+        obs = r_buffer.obs[cur_step].view(E * N, -1)
+        actions, logp, _ = self.policy.actor(obs)
+        if self.trainer.dedup_critic:
+            values = self.policy.critic(r_buffer.share_obs_env[cur_step])[0].view(E, 1, 1).expand(E, N, 1)
+        else:
+            values = self.policy.critic(r_buffer.share_obs[cur_step].reshape(E * N, -1))[0].view(E, N, 1)
+        return values, actions.view(E, N, -1).contiguous(), logp.view(E, N, 1)
+
+    def insert(self, data, r_buffer):
+        """masks = 0 where the env finished (learner.py:254-276); obs[t+1] is already in place."""
+        out, values, actions, action_log_probs = data
+        E, N = r_buffer.n_rollout_threads, self.n_agents
+        masks = (1.0 - out["done"].to(torch.float32)).view(E, 1, 1).expand(E, N, 1)
+        rewards = out["reward"].view(E, 1, 1).expand(E, N, 1)
+        r_buffer.insert(None, None, None, None, actions, action_log_probs, values, rewards, masks)
+
+    @torch.no_grad()
+    def compute(self, r_buffer):
+        """bootstrap value + GAE (learner.py:278-287 -> HIP scan)."""
+        self.trainer.prep_rollout()
+        E, N = r_buffer.n_rollout_threads, self.n_agents
+        next_values = self.policy.critic(r_buffer.share_obs_env[-1])[0].view(E, 1, 1).expand(E, N, 1)
+        r_buffer.compute_returns(next_values, self.trainer.value_normalizer)
+
+    # ---- update (learner.py:292-300) ---------------------------------------------------------------------
+    def rl_update(self):
+        self.trainer.prep_training()
+        info = self.trainer.train(buffer=self.rl_buffer, update_actor=True)
+        self.rl_buffer.after_update()
+        return info
+
+    def log(self, iter_, **kwargs):
+        if self.rank != 0:
+            return
+        now = time.time()
+        print("")
+        print("******** iter: %d, iter_time: %.2fs, total_time: %.2fs, agent-env-steps/s (train rollouts + updates): %.0f"
+              % (iter_, now - self._check_time, now - self._start_time,
+                 self.total_env_steps * self.n_agents / max(now - self._start_time, 1e-9)))
+        for key, value in kwargs.items():
+            print("%s" % key + "".join([", %s: %.4f" % (k, v) for k, v in value.items()]))
+        self._check_time = now
+
+    def save_model(self, save_path):
+        self.trainer.save_model(save_path)
+
+    def load_model(self, load_path):
+        self.trainer.load_model(load_path)

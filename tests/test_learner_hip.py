@@ -1,0 +1,110 @@
+"""-m gpu: the device-resident MAPPO loop end to end (env kernel -> policy GEMMs -> buffer -> GAE
+kernel -> PPO update), the numpy drop-in surface of the vec-env, and the single-env DCEnv view."""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import PKG, GOLDEN, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(**over):
+    cfg = {}
+    for f in ("config/env_config/dcc.yaml", "config/algo_config/mappo.yaml", "config/expt.yaml"):
+        cfg.update(yaml.safe_load(open(os.path.join(PKG, f))))
+    cfg.update(over)
+    return Namespace(**cfg)
+
+
+def test_vec_env_numpy_surface_matches_reference_contract():
+    """make_env(cfg) -> reset()/step() with the shapes/dtypes of wrappers.py:161-165 and the golden values."""
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from envs.make_env import make_env
+    z, c = load_case(os.path.join(GOLDEN, "env_n4m20_shipped.npz"))
+    cfg = _cfg(n_rollout_threads=c["E"], num_agents=4, num_pois=20, comm_r_scale=0.9)
+    env = make_env(cfg)
+    assert env.observation_space[0].shape == (110,) and env.share_observation_space[0].shape == (440,)
+    assert env.action_space[0].__class__.__name__ == "Box" and env.action_space[0].shape == (2,)
+    obs = env.reset()
+    assert obs.shape == (c["E"], 4, 110)
+    np.testing.assert_array_equal(obs[0], z["reset_obs"])
+    for t in range(40):
+        a = z["actions"][t].copy()
+        a0 = a.copy()
+        obs, rew, done, infos = env.step(a)
+        assert np.array_equal(a, a0)                        # the caller's actions are not mutated (Q2)
+        assert rew.shape == (c["E"], 4, 1) and done.shape == (c["E"], 4) and done.dtype == bool
+        np.testing.assert_allclose(rew[:, 0, 0], z["reward"][t], rtol=1e-5, atol=1e-5)
+        assert np.array_equal(done[:, 0], z["done"][t].astype(bool))
+        assert len(infos) == c["E"]
+        np.testing.assert_allclose([i["coverage_rate"] for i in infos], z["coverage"][t], atol=1e-6)
+    env.close()
+
+
+def test_single_env_dcenv_view():
+    from envs.mpe.uav_dcc import DCEnv
+    z, c = load_case(os.path.join(GOLDEN, "env_n4m20_shipped.npz"))
+    env = DCEnv("coverage", num_agents=4, num_pois=20, comm_r_scale=0.9)
+    obs_n = env.reset()
+    assert len(obs_n) == 4 and obs_n[0].shape == (110,)
+    o, r, d, info = env.step(np.zeros((4, 2)))
+    assert abs(r[0] - (-56.51319293982027)) < 1e-3 and d == [False] * 4 and info["coverage_rate"] == 0.0
+    env.close()
+
+
+def test_learner_runs_and_improves_nothing_breaks(tmp_path):
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    cfg = _cfg(n_rollout_threads=64, n_eval_rollout_threads=8, num_agents=4, num_pois=16, max_ep_len=20, n_iters=2,
+               ppo_epoch=3, algo_hidden_size=64, save_model=True, save_interval=2, eval_interval=2,
+               main_save_path=str(tmp_path))
+    lr = Learner(cfg)
+    lr.train()
+    info = lr.trainer.train(lr.rl_buffer)
+    for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"):
+        assert np.isfinite(info[k]), k
+    assert os.path.exists(os.path.join(lr.output_path, "models_2.pt", "agent.pkl"))
+    # rollout invariants on the device buffer
+    b = lr.rl_buffer
+    assert torch.isfinite(b.returns).all() and torch.isfinite(b.obs).all()
+    assert bool(((b.masks == 0) | (b.masks == 1)).all())
+    # values identical across the agents of an env (centralised critic evaluated once per env)
+    assert float((b.value_preds - b.value_preds[:, :, :1]).abs().max()) == 0.0
+    # checkpoint round trip
+    w0 = lr.policy.actor.state_dict()["act.action_out.fc_mean.weight"].clone()
+    lr.policy.actor.state_dict()["act.action_out.fc_mean.weight"].zero_()
+    lr.load_model(os.path.join(lr.output_path, "models_2.pt"))
+    lr2_w = lr.policy.actor.state_dict()["act.action_out.fc_mean.weight"]
+    assert lr2_w.abs().sum() > 0
+    ptu.set_gpu_mode(False)
+
+
+def test_rollout_obs_in_buffer_equal_oracle_replay(oracle_mod):
+    """The observations the kernel wrote into the rollout buffer are those the oracle produces when it is
+    fed the actions stored in the buffer (policy-driven actions, auto-resets included)."""
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    from envs.hip_vec_env import load_pois
+    cfg = _cfg(n_rollout_threads=16, n_eval_rollout_threads=0, num_agents=4, num_pois=16, max_ep_len=30, n_iters=1,
+               ppo_epoch=1, algo_hidden_size=32, save_model=False)
+    lr = Learner(cfg)
+    torch.manual_seed(0)
+    lr.rollout(lr.rl_buffer, lr.train_envs)
+    b = lr.rl_buffer
+    orc = oracle_mod.OracleEnv(16, 4, 16, load_pois(16), 0.2, 0.4, 0.95, 0.0)
+    o = orc.reset()
+    np.testing.assert_array_equal(b.obs[0].cpu().numpy(), o.astype(np.float32))
+    for t in range(30):
+        ref = orc.step(b.actions[t].cpu().numpy())
+        np.testing.assert_allclose(b.obs[t + 1].cpu().numpy(), ref["obs"].astype(np.float32), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(b.rewards[t, :, 0, 0].cpu().numpy(), ref["reward"], rtol=1e-5, atol=1e-5)
+        assert np.array_equal(1 - b.masks[t + 1, :, 0, 0].cpu().numpy(), ref["done"])
+    ptu.set_gpu_mode(False)
