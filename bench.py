@@ -94,6 +94,63 @@ def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, budget_s=10.0):
             "value_1core": rate1}
 
 
+def bench_mappo(args):
+    """BASELINE config 3: 8 UAV x 64 PoI x 4096 envs per GPU, T=150 policy-driven env steps, HIP GAE scan and
+    ppo_epoch full-batch PPO epochs per iteration (fp32, critic evaluated once per env).  Not the headline."""
+    import yaml
+    from argparse import Namespace
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, local_rank)
+    cfg = {}
+    for f in ("config/env_config/dcc.yaml", "config/algo_config/mappo.yaml", "config/expt.yaml"):
+        cfg.update(yaml.safe_load(open(os.path.join(PKG, f))))
+    cfg.update(num_agents=args.agents, num_pois=args.pois, n_rollout_threads=args.envs * world, n_eval_rollout_threads=0,
+               max_ep_len=args.steps_per_launch, ppo_epoch=args.ppo_epoch, save_model=False, n_iters=1,
+               comm_force_scale=args.comm_force_scale, r_comm=args.r_comm)
+    from learner import Learner
+    lr = Learner(Namespace(**cfg))
+    rank = lr.rank
+
+    def one_iter():
+        t0 = time.perf_counter()
+        info = lr.rollout(lr.rl_buffer, lr.train_envs)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        tinfo = lr.rl_update()
+        torch.cuda.synchronize()
+        return t1 - t0, time.perf_counter() - t1, info, tinfo
+
+    one_iter()  # warmup (hipBLASLt heuristics, allocator)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr = tu = 0.0
+    for _ in range(args.iters):
+        a, b, info, tinfo = one_iter()
+        tr += a; tu += b
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    E, N, T = args.envs, args.agents, args.steps_per_launch
+    steps = args.iters * T
+    res = {"metric": "agent_env_steps_per_sec", "value": world * E * N * steps / dt, "unit": "agent-env-steps/s",
+           "n_gpus": world, "steps": steps, "warmup": T, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64 env state / f32 MLPs", "data": "synthetic",
+           "config": {"workload": "c3: %d UAV x %d PoI x %d envs per GPU, full MAPPO iteration = %d policy-driven env "
+                                  "steps + HIP GAE + %d full-batch PPO epochs" % (N, args.pois, E, T, args.ppo_epoch),
+                      "rollout_s_per_iter": tr / args.iters, "update_s_per_iter": tu / args.iters,
+                      "rollout_agent_env_steps_per_sec": world * E * N * T / (tr / args.iters),
+                      "train_info": {k: float(v) for k, v in tinfo.items()}, "rollout_info": info}}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,7 +166,13 @@ def main():
                     help="hbm: read pre-generated actions [T,E,N,2] (full byte contract); rng: draw in-kernel")
     ap.add_argument("--no-obs", action="store_true", help="skip the obs write (state-only variant, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["env", "mappo"], default="env",
+                    help="env: BASELINE config 2 (headline); mappo: config 3, full rollout + GAE + PPO update")
+    ap.add_argument("--iters", type=int, default=2, help="--mode mappo: timed training iterations")
+    ap.add_argument("--ppo-epoch", type=int, default=15)
     args = ap.parse_args()
+    if args.mode == "mappo":
+        return bench_mappo(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
