@@ -170,7 +170,9 @@ struct Stager {
 // CU, shared by the 16 resident waves) is relieved of loop control and index arithmetic.  NC = 0 is
 // the generic runtime-size kernel.
 template <int PPL, int ACT, bool FORCE, int NC, int MC>
-__global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
+// Register budget: 4 waves/SIMD (<=128 VGPRs) keeps all 1024 workgroups of a 4096-env batch co-resident;
+// kernels that hold >= 8 PoIs per lane or the pull-force path trade occupancy for registers instead of spilling.
+__global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? 3 : 4))) void dcc_env_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -198,14 +200,23 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
     double px = 0, py = 0, vx = 0, vy = 0;
     float en[PPL];
     unsigned dmask = 0;  // bit q: PoI q*64+lane is done
-    double pjx[PPL], pjy[PPL];
+    // PoI coordinates: in registers for <= 4 PoIs per lane, re-read from the LDS table otherwise
+    constexpr bool PJ_REG = PPL <= 4;
+    constexpr int NPJ = PJ_REG ? PPL : 1;
+    double pjx_r[NPJ], pjy_r[NPJ];
 #pragma unroll
-    for (int q = 0; q < PPL; ++q) {
+    for (int q = 0; q < PPL; ++q) en[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NPJ; ++q) {
         const int j = q * 64 + lane;
-        en[q] = 0.f;
-        pjx[q] = 0; pjy[q] = 0;
-        if (j < M) { const double2 pj = s_poi[j]; pjx[q] = pj.x; pjy[q] = pj.y; }
+        pjx_r[q] = 0; pjy_r[q] = 0;
+        if (PJ_REG && j < M) { const double2 pj = s_poi[j]; pjx_r[q] = pj.x; pjy_r[q] = pj.y; }
     }
+    auto poi_of = [&](int q) -> double2 {
+        if (PJ_REG) return make_double2(pjx_r[PJ_REG ? q : 0], pjy_r[PJ_REG ? q : 0]);
+        const int j = q * 64 + lane;
+        return s_poi[j < M ? j : 0];
+    };
     if (p.mode == 0) {
         if (lane < N) {
             const double2 a = p.pos[(size_t)env * N + lane], b = p.vel[(size_t)env * N + lane];
@@ -233,7 +244,8 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
 #pragma unroll
             for (int i = 0; i < (CACHE ? NC : 0); ++i) {
                 const double2 xa = apos[i];
-                cdx[q * NC + i] = (float)(pjx[q] - xa.x); cdy[q * NC + i] = (float)(pjy[q] - xa.y);
+                const double2 pj = poi_of(q);
+                cdx[q * NC + i] = (float)(pj.x - xa.x); cdy[q * NC + i] = (float)(pj.y - xa.y);
             }
     }
     // Every value loaded from HBM above is consumed here, once: the step loop then contains no
@@ -440,13 +452,14 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
             for (int q = 0; q < PPL; ++q) {
                 const int j = q * 64 + lane;
                 const bool valid = j < M;
+                const double2 pj = poi_of(q);
                 int cnt = 0, amin = 0;
                 double smin = 1.7976931348623157e308;
                 bool near = false;
 #pragma unroll UNR_F
                 for (int i = 0; i < N; ++i) {
                     const double2 xa = apos[i];
-                    const double dx = pjx[q] - xa.x, dy = pjy[q] - xa.y;
+                    const double dx = pj.x - xa.x, dy = pj.y - xa.y;
                     if (CACHE) { cdx[q * NC + i] = (float)dx; cdy[q * NC + i] = (float)dy; }
                     const double s = __builtin_fma(dy, dy, dx * dx);
                     cnt += (s <= p.sq_cover) ? 1 : 0;      // ||p_j - x_i|| <= r_cover (CW:164-165)
@@ -461,7 +474,7 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
                     double dmn = 0.0;
                     for (int i = 0; i < N; ++i) {
                         const double2 xa = apos[i];
-                        const double d = norm2(pjx[q] - xa.x, pjy[q] - xa.y);
+                        const double d = norm2(pj.x - xa.x, pj.y - xa.y);
                         if (i == 0 || d < dmn) { dmn = d; amin = i; }
                     }
                 }
@@ -511,7 +524,7 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
 #pragma unroll
                     for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                        for (int i = 0; i < (CACHE ? NC : 0); ++i) { cdx[q * NC + i] = (float)pjx[q]; cdy[q * NC + i] = (float)pjy[q]; }
+                        for (int i = 0; i < (CACHE ? NC : 0); ++i) { const double2 pj = poi_of(q); cdx[q * NC + i] = (float)pj.x; cdy[q * NC + i] = (float)pj.y; }
                 }
                 wave_fence();
             }
@@ -548,8 +561,9 @@ __global__ __launch_bounds__(kBlock, 4) void dcc_env_kernel(const KParams p) {
                         float* dst = st.reserve(i * D + H + q * kTileFloats, 5 * cntj, lane);
                         if (lane < cntj) {
                             float* d5 = dst + 5 * lane;
-                            d5[0] = CACHE ? cdx[CACHE ? q * NC + i : 0] : (float)(pjx[q] - xi.x);
-                            d5[1] = CACHE ? cdy[CACHE ? q * NC + i : 0] : (float)(pjy[q] - xi.y);
+                            const double2 pj = poi_of(q);
+                            d5[0] = CACHE ? cdx[CACHE ? q * NC + i : 0] : (float)(pj.x - xi.x);
+                            d5[1] = CACHE ? cdy[CACHE ? q * NC + i : 0] : (float)(pj.y - xi.y);
                             d5[2] = en[q];
                             d5[3] = p.m_energy_f;
                             d5[4] = ((dmask >> q) & 1u) ? 1.f : 0.f;
