@@ -205,3 +205,101 @@ def test_full_size_properties_config2():
     assert float(vel.norm(dim=-1).max()) <= 0.5 + 1e-6
     assert bool(torch.isfinite(out["reward64"]).all())
     assert 0 <= int(out["assign"].max()) < N
+
+
+def test_unaligned_obs_pointer_uses_scalar_store_path(oracle_mod):
+    """An obs buffer that is only 4-byte aligned cannot take the float4 path: results must not change."""
+    import dcc_hip
+    E, N, M = 5, 8, 64
+    poi = np.load(os.path.join(os.path.dirname(__file__), "golden", "pos_pois.npy"))[:M]
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi)
+    orc = oracle_mod.OracleEnv(E, N, M, poi)
+    env.reset(); orc.reset()
+    backing = torch.zeros(E * N * env.D + 1, dtype=torch.float32, device=env.device)
+    obs = backing[1:].view(E, N, env.D)            # data_ptr % 16 == 4
+    assert obs.data_ptr() % 16 == 4
+    for t in range(6):
+        a = oracle_mod.rng_actions(3, t, E, N)
+        out = env.alloc_out(obs=False); out["obs"] = obs
+        env.step(torch.from_numpy(a).to(env.device), out)
+        ref = orc.step(a)
+        np.testing.assert_allclose(obs.cpu().numpy(), ref["obs"].astype(np.float32), rtol=0, atol=OBS_TOL)
+    assert float(backing[0]) == 0.0                # nothing written in front of the block
+
+
+def test_odd_row_length_not_multiple_of_four(oracle_mod):
+    """N*D % 4 != 0 (N=3, M=7: 3*41 = 123 floats per env): per-env blocks are not 16-byte aligned."""
+    import dcc_hip
+    E, N, M = 9, 3, 7
+    rs = np.random.RandomState(1)
+    poi = rs.uniform(-1, 1, (M, 2))
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.3, 0.25, 0.9, 1.0)
+    orc = oracle_mod.OracleEnv(E, N, M, poi, 0.3, 0.25, 0.9, 1.0)
+    assert (N * env.D) % 4 != 0
+    np.testing.assert_array_equal(env.reset().cpu().numpy(), orc.reset().astype(np.float32))
+    for t in range(10):
+        a = oracle_mod.rng_actions(9, t, E, N)
+        out = env.step(torch.from_numpy(a).to(env.device))
+        ref = orc.step(a)
+        np.testing.assert_allclose(out["obs"].cpu().numpy(), ref["obs"].astype(np.float32), rtol=0, atol=OBS_TOL)
+        assert np.array_equal(out["connect_s"].cpu().numpy(), ref["connect_s"])
+
+
+def test_single_env_and_null_outputs(oracle_mod):
+    import dcc_hip
+    poi = np.load(os.path.join(os.path.dirname(__file__), "golden", "pos_pois.npy"))[:20]
+    env = dcc_hip.HipCoverageEnv(1, 4, 20, poi, 0.2, 0.4, 0.9, 0.0)
+    orc = oracle_mod.OracleEnv(1, 4, 20, poi, 0.2, 0.4, 0.9, 0.0)
+    env.reset(); orc.reset()
+    a = oracle_mod.rng_actions(1, 0, 1, 4)
+    out = env.step(torch.from_numpy(a).to(env.device), dict(done=torch.zeros(1, dtype=torch.uint8, device=env.device)))
+    ref = orc.step(a)
+    assert int(out["done"][0]) == int(ref["done"][0])          # only `done` requested: every other output skipped
+    np.testing.assert_array_equal(env.get_state()["pos"].cpu().numpy(), orc.get_state()["pos"])
+
+
+def test_argument_validation_raises():
+    import dcc_hip
+    poi = np.zeros((4, 2))
+    env = dcc_hip.HipCoverageEnv(2, 3, 4, poi)
+    dev = env.device
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(2, 3, 3, device=dev))                      # wrong shape
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(2, 3, 2, dtype=torch.float16, device=dev))  # wrong dtype
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(2, 3, 2))                                    # host tensor
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(2, 3, 2, device=dev), dict(reward=torch.zeros(3, device=dev)))
+    with pytest.raises(dcc_hip.DccError):
+        dcc_hip.HipCoverageEnv(2, 65, 4, np.zeros((4, 2)))
+    with pytest.raises(dcc_hip.DccError):
+        dcc_hip.HipCoverageEnv(2, 3, 4, poi, comm_r_scale=0.0, comm_force_scale=0.5)
+    L = env.lib
+    assert L.dcc_env_rollout(env._h, 0, None, 0, 0, 0, 2, None, None) == -1 and b"K must" in L.dcc_last_error()
+
+
+def test_connectivity_flags_match_graph_connectivity():
+    """Property: connect <=> graph(A) connected; connect_ <=> connect and no A_-isolated node (N >= 3)."""
+    import dcc_hip
+    E, N, M = 256, 7, 8
+    rs = np.random.RandomState(3)
+    env = dcc_hip.HipCoverageEnv(E, N, M, rs.uniform(-1, 1, (M, 2)), 0.2, 0.25, 0.8, 0.0)
+    env.reset()
+    pos = rs.uniform(-1, 1, (E, N, 2)) * rs.uniform(0.2, 1.0, (E, 1, 1))
+    env.set_state(pos=pos, vel=np.zeros((E, N, 2)))
+    out = env.step(torch.zeros(E, N, 2, device=env.device))
+    d = np.linalg.norm(pos[:, :, None] - pos[:, None], axis=-1)
+    A = (d < 0.5) & ~np.eye(N, dtype=bool); As = (d < 0.8 * 0.5) & ~np.eye(N, dtype=bool)
+    conn = np.zeros(E, bool)
+    for e in range(E):
+        seen = {0}; front = [0]
+        while front:
+            x = front.pop()
+            for y in np.nonzero(A[e, x])[0]:
+                if y not in seen:
+                    seen.add(y); front.append(y)
+        conn[e] = len(seen) == N
+    assert np.array_equal(out["connect"].cpu().numpy().astype(bool), conn)
+    assert np.array_equal(out["connect_s"].cpu().numpy().astype(bool), conn & As.any(1).all(1))
+    assert 0.1 < conn.mean() < 0.9
