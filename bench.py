@@ -166,6 +166,8 @@ def main():
                     help="hbm: read pre-generated actions [T,E,N,2] (full byte contract); rng: draw in-kernel")
     ap.add_argument("--no-obs", action="store_true", help="skip the obs write (state-only variant, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm-r-scale", type=float, default=0.95, help="0 disables the connectivity flags (profiling aid)")
+    ap.add_argument("--no-assign", action="store_true", help="skip the PoI-assignment output (profiling aid)")
     ap.add_argument("--mode", choices=["env", "mappo"], default="env",
                     help="env: BASELINE config 2 (headline); mappo: config 3, full rollout + GAE + PPO update")
     ap.add_argument("--iters", type=int, default=2, help="--mode mappo: timed training iterations")
@@ -196,14 +198,14 @@ def main():
     from oracle import oracle  # only for generating the synthetic action stream + cpu_baseline leg
 
     E, N, M, T = args.envs, args.agents, args.pois, args.steps_per_launch
-    r_cover, crs, cfs, r_comm = 0.2, 0.95, args.comm_force_scale, args.r_comm
+    r_cover, crs, cfs, r_comm = 0.2, args.comm_r_scale, args.comm_force_scale, args.r_comm
     poi_all = np.load(os.path.join(PKG, "envs", "mpe", "pos_pois.npy"))
     if M > len(poi_all):
         poi_all = np.concatenate([poi_all, np.random.RandomState(2024).uniform(-1, 1, (M - len(poi_all), 2))])
     poi = poi_all[:M]
     env = dcc_hip.HipCoverageEnv(E, N, M, poi, r_cover, r_comm, crs, cfs, device=local_rank)
     env.reset()
-    out = env.alloc_out(T, obs=not args.no_obs, assign=True)
+    out = env.alloc_out(T, obs=not args.no_obs, assign=not args.no_assign)
     actions = None
     if args.actions == "hbm":
         acts = np.stack([oracle.rng_actions(0, k, E, N, rank * E, world * E) for k in range(T)])

@@ -21,9 +21,23 @@ class _Cfg(ctypes.Structure):
 
 
 def build(force=False):
+    """(Re)build libdcc_oracle.so when it is missing or older than its source.  Serialised with a file
+    lock: the ranks of a multi-GPU bench import this module at the same time."""
+    import fcntl
     src = os.path.join(_HERE, "dcc_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    def stale():
+        return force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+    if stale():
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if stale():
+                    tmp = _LIB_PATH + ".tmp%d" % os.getpid()
+                    subprocess.check_call(["gcc", "-O2", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+                                           "-fvisibility=hidden", "-std=c11", "-shared", "-o", tmp, src, "-lm"])
+                    os.replace(tmp, _LIB_PATH)   # atomic: a concurrent dlopen never sees a half-written file
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     return _LIB_PATH
 
 
