@@ -186,13 +186,19 @@ def main():
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the env hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # DCC_BENCH_BACKEND=gloo is a test hook: several ranks may then share one GPU (rendezvous over gloo)
+    backend = os.environ.get("DCC_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import dcc_hip
     from oracle import oracle  # only for generating the synthetic action stream + cpu_baseline leg
@@ -203,7 +209,7 @@ def main():
     if M > len(poi_all):
         poi_all = np.concatenate([poi_all, np.random.RandomState(2024).uniform(-1, 1, (M - len(poi_all), 2))])
     poi = poi_all[:M]
-    env = dcc_hip.HipCoverageEnv(E, N, M, poi, r_cover, r_comm, crs, cfs, device=local_rank)
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi, r_cover, r_comm, crs, cfs, device=local_dev)
     env.reset()
     out = env.alloc_out(T, obs=not args.no_obs, assign=not args.no_assign)
     actions = None
@@ -247,7 +253,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

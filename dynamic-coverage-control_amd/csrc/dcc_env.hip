@@ -236,21 +236,6 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? 3 : 4))) void dcc_
     }
     if (lane < N) { apos[lane] = make_double2(px, py); avel[lane] = make_double2(vx, vy); }
     wave_fence();
-    // Specialised kernels keep the float32 (p_j - x_i) of the energy pass for the observation rows
-    // (identical values: same float64 subtraction, same cast) instead of recomputing them.
-    constexpr bool CACHE = SPEC && !FORCE && (NC * PPL <= 8);
-    constexpr int NCACHE = CACHE ? NC * PPL : 1;
-    float cdx[NCACHE], cdy[NCACHE];
-    if (CACHE) {
-#pragma unroll
-        for (int q = 0; q < PPL; ++q)
-#pragma unroll
-            for (int i = 0; i < (CACHE ? NC : 0); ++i) {
-                const double2 xa = apos[i];
-                const double2 pj = poi_of(q);
-                cdx[q * NC + i] = (float)(pj.x - xa.x); cdy[q * NC + i] = (float)(pj.y - xa.y);
-            }
-    }
     // Every value loaded from HBM above is consumed here, once: the step loop then contains no
     // use of a pending load, so the compiler never has to drain the obs stores (s_waitcnt vmcnt(0))
     // of earlier steps in the middle of a step.
@@ -457,22 +442,23 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? 3 : 4))) void dcc_
                 const bool valid = j < M;
                 const double2 pj = poi_of(q);
                 int cnt = 0, amin = 0;
-                double smin = 1.7976931348623157e308;
-                bool near = false;
+                // smin: running minimum of the radicand; sprev: the running minimum just before its last
+                // displacement = the smallest radicand among the agents in front of the argmin.  If sprev is
+                // within a few ulp of smin the rounded distances could tie (np.argmin would then keep the
+                // earlier agent): that case, practically never taken, is resolved exactly below.
+                double smin = 1.7976931348623157e308, sprev = 1.7976931348623157e308;
 #pragma unroll UNR_F
                 for (int i = 0; i < N; ++i) {
                     const double2 xa = apos[i];
                     const double dx = pj.x - xa.x, dy = pj.y - xa.y;
-                    if (CACHE) { cdx[q * NC + i] = (float)dx; cdy[q * NC + i] = (float)dy; }
                     const double s = __builtin_fma(dy, dy, dx * dx);
                     cnt += (s <= p.sq_cover) ? 1 : 0;      // ||p_j - x_i|| <= r_cover (CW:164-165)
-                    if (s < smin) {
-                        // an earlier agent within a few ulp above the new minimum could tie on the
-                        // rounded distance: resolve exactly below
-                        near = near || (smin <= s * 1.0000000000000009);
-                        smin = s; amin = i;
-                    }
+                    const bool lt = s < smin;
+                    sprev = lt ? smin : sprev;
+                    smin = lt ? s : smin;
+                    amin = lt ? i : amin;
                 }
+                const bool near = sprev <= smin * 1.0000000000000009;
                 if (near && p.assign) {  // exact first-minimum on the rounded distances (practically never taken)
                     double dmn = 0.0;
                     for (int i = 0; i < N; ++i) {
@@ -523,12 +509,6 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? 3 : 4))) void dcc_
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) en[q] = 0.f;
                 if (lane < N) { apos[lane] = make_double2(0.0, 0.0); avel[lane] = make_double2(0.0, 0.0); }
-                if (CACHE) {
-#pragma unroll
-                    for (int q = 0; q < PPL; ++q)
-#pragma unroll
-                        for (int i = 0; i < (CACHE ? NC : 0); ++i) { const double2 pj = poi_of(q); cdx[q * NC + i] = (float)pj.x; cdy[q * NC + i] = (float)pj.y; }
-                }
                 wave_fence();
             }
         }
@@ -565,8 +545,8 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? 3 : 4))) void dcc_
                         if (lane < cntj) {
                             float* d5 = dst + 5 * lane;
                             const double2 pj = poi_of(q);
-                            d5[0] = CACHE ? cdx[CACHE ? q * NC + i : 0] : (float)(pj.x - xi.x);
-                            d5[1] = CACHE ? cdy[CACHE ? q * NC + i : 0] : (float)(pj.y - xi.y);
+                            d5[0] = (float)(pj.x - xi.x);
+                            d5[1] = (float)(pj.y - xi.y);
                             d5[2] = en[q];
                             d5[3] = p.m_energy_f;
                             d5[4] = ((dmask >> q) & 1u) ? 1.f : 0.f;

@@ -303,3 +303,36 @@ def test_connectivity_flags_match_graph_connectivity():
     assert np.array_equal(out["connect"].cpu().numpy().astype(bool), conn)
     assert np.array_equal(out["connect_s"].cpu().numpy().astype(bool), conn & As.any(1).all(1))
     assert 0.1 < conn.mean() < 0.9
+
+
+def test_assignment_index_tie_on_rounded_distance(oracle_mod):
+    """np.argmin works on the ROUNDED distances: two agents whose squared distances differ by an ulp or
+    two can tie after the square root, and the earlier agent must win.  The kernel compares radicands
+    and has an exact slow path for this case; build such near-ties on purpose and compare with the oracle."""
+    import dcc_hip
+    E, N, M = 64, 4, 3
+    poi = np.array([[0.0, 0.0], [0.5, -0.25], [-0.7, 0.3]])
+    rs = np.random.RandomState(0)
+    pos = np.zeros((E, N, 2))
+    n_tie = 0
+    for e in range(E):
+        dx = rs.uniform(0.3, 0.9)
+        ulp = np.spacing(dx * dx)
+        dy = np.sqrt(ulp) * rs.choice([0.6, 0.8, 1.0, 1.3, 1.7, 2.5])
+        pos[e, 0] = (dx, dy)          # slightly FARTHER from PoI 0, but listed first
+        pos[e, 1] = (dx, 0.0)
+        pos[e, 2] = (2.0 * dx, 0.1)
+        pos[e, 3] = (-1.2 * dx, 0.4)
+        d0 = np.sqrt(np.float64(dy) * dy + dx * dx) if False else None
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.05, 0.4, 0.9, 0.0)
+    orc = oracle_mod.OracleEnv(E, N, M, poi, 0.05, 0.4, 0.9, 0.0)
+    env.reset(); orc.reset()
+    env.set_state(pos=pos, vel=np.zeros((E, N, 2)))
+    orc.set_state(pos=pos, vel=np.zeros((E, N, 2)))
+    a = np.zeros((E, N, 2), np.float32)
+    out = env.step(torch.from_numpy(a).to(env.device))
+    ref = orc.step(a)
+    got = out["assign"].cpu().numpy().astype(np.int32)
+    assert np.array_equal(got, ref["assign"])
+    n_tie = int((ref["assign"][:, 0] == 0).sum())
+    assert 0 < n_tie < E, "the construction must produce both ties (index 0 wins) and non-ties (index 1 wins)"
