@@ -108,7 +108,8 @@ def bench_mappo(args):
         cfg.update(yaml.safe_load(open(os.path.join(PKG, f))))
     cfg.update(num_agents=args.agents, num_pois=args.pois, n_rollout_threads=args.envs * world, n_eval_rollout_threads=0,
                max_ep_len=args.steps_per_launch, ppo_epoch=args.ppo_epoch, save_model=False, n_iters=1,
-               comm_force_scale=args.comm_force_scale, r_comm=args.r_comm)
+               comm_force_scale=args.comm_force_scale, r_comm=args.r_comm, amp_bf16=args.amp_bf16,
+               use_hip_graph=args.graph)
     from learner import Learner
     lr = Learner(Namespace(**cfg))
     rank = lr.rank
@@ -122,7 +123,8 @@ def bench_mappo(args):
         torch.cuda.synchronize()
         return t1 - t0, time.perf_counter() - t1, info, tinfo
 
-    one_iter()  # warmup (hipBLASLt heuristics, allocator)
+    one_iter()  # warmup (hipBLASLt heuristics, allocator; eager rollout + hipGraph capture)
+    one_iter()  # first graph replay
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -172,6 +174,8 @@ def main():
                     help="env: BASELINE config 2 (headline); mappo: config 3, full rollout + GAE + PPO update")
     ap.add_argument("--iters", type=int, default=2, help="--mode mappo: timed training iterations")
     ap.add_argument("--ppo-epoch", type=int, default=15)
+    ap.add_argument("--amp-bf16", action="store_true", help="--mode mappo: bf16 autocast in the PPO update")
+    ap.add_argument("--graph", action="store_true", help="--mode mappo: capture the rollout into a hipGraph")
     args = ap.parse_args()
     if args.mode == "mappo":
         return bench_mappo(args)

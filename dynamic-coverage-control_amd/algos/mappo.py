@@ -126,6 +126,9 @@ class MAPPOTrainer:
         # reference quirk Q4 (doubled surrogate) on by default; critic de-duplication is exact
         self.double_surrogate = bool(getattr(cfg, "double_surrogate", True))
         self.dedup_critic = bool(getattr(cfg, "dedup_critic", True))
+        # optional bf16 autocast of the update's GEMMs (MFMA bf16 = 16x the f32-MFMA rate); off by default
+        # because the reference trains in fp32
+        self.amp_bf16 = bool(getattr(cfg, "amp_bf16", False)) and ptu.device.type == "cuda"
         self.value_normalizer = ValueNorm(1, device=ptu.device) if self._use_valuenorm else None
 
     # ---- losses ---------------------------------------------------------------------------------
@@ -162,9 +165,11 @@ class MAPPOTrainer:
         value_preds_batch, return_batch, active_masks_batch = t(value_preds_batch), t(return_batch), t(active_masks_batch)
         obs_batch, share_obs_batch, actions_batch = t(obs_batch), t(share_obs_batch), t(actions_batch)
 
-        action_log_probs, dist_entropy = self.policy.actor.evaluate_actions(
-            obs_batch, rnn_states_batch, actions_batch, masks_batch, available_actions_batch, active_masks_batch)
-        values = self.policy.critic(share_obs_batch)[0]
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp_bf16):
+            action_log_probs, dist_entropy = self.policy.actor.evaluate_actions(
+                obs_batch, rnn_states_batch, actions_batch, masks_batch, available_actions_batch, active_masks_batch)
+            values = self.policy.critic(share_obs_batch)[0]
+        action_log_probs, dist_entropy, values = action_log_probs.float(), dist_entropy.float(), values.float()
         if values.shape[0] != obs_batch.shape[0]:
             n_rep = obs_batch.shape[0] // values.shape[0]
             values = values.unsqueeze(1).expand(-1, n_rep, -1).reshape(-1, 1)

@@ -43,7 +43,7 @@ def _to_namespace(cfg):
 class Learner:
     def __init__(self, cfg):
         self.cfg = _to_namespace(cfg)
-        for k, v in (("double_surrogate", True), ("dedup_critic", True)):
+        for k, v in (("double_surrogate", True), ("dedup_critic", True), ("use_hip_graph", False), ("amp_bf16", False)):
             if not hasattr(self.cfg, k):
                 setattr(self.cfg, k, v)
         self.rank, self.world = ptu.init_distributed() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
@@ -96,6 +96,12 @@ class Learner:
                 json.dump({k: v for k, v in vars(self.cfg).items()}, f, indent=4, default=str)
         self._start_time = self._check_time = time.time()
         self.total_env_steps = 0
+        # Optional (cfg.use_hip_graph): after one eager pass each (buffer, envs) pair is captured into a
+        # hipGraph and replayed (parameters are updated in place, so the graph always sees the current
+        # policy).  Measured at config 3: no gain -- the step is bound by the fp32 GEMMs of the policy
+        # forward (0.88 ms/step), not by launches -- so it is off by default.
+        self._graphs = {}
+        self.use_hip_graph = bool(self.cfg.use_hip_graph) and ptu.device.type == "cuda"
 
     def _make_buffer(self, envs):
         bcfg = copy.deepcopy(self.cfg)
@@ -126,7 +132,8 @@ class Learner:
 
     # ---- rollout (learner.py:178-214) -------------------------------------------------------------------
     @torch.no_grad()
-    def rollout(self, r_buffer, r_envs, is_render=False, iter_=0):
+    def _rollout_body(self, r_buffer, r_envs):
+        """warmup + T x (collect -> env step -> insert) + compute, all asynchronous on the current stream."""
         self.warmup(r_buffer, r_envs)
         rew_sum = torch.zeros((), dtype=torch.float64, device=ptu.device)
         cov_max = torch.zeros(r_envs.n_envs, dtype=torch.float32, device=ptu.device)
@@ -137,8 +144,32 @@ class Learner:
             rew_sum += out["reward"].double().mean()
             cov_max = torch.maximum(cov_max, out["coverage"])
         self.compute(r_buffer)
+        return torch.stack([rew_sum, cov_max.double().mean()])
+
+    @torch.no_grad()
+    def rollout(self, r_buffer, r_envs, is_render=False, iter_=0):
+        if is_render:
+            raise NotImplementedError("rendering is out of scope (no display on a GPU node)")
+        key = id(r_buffer)
+        if self.use_hip_graph and key in self._graphs:
+            graph, stats = self._graphs[key]
+            graph.replay()
+        else:
+            stats = self._rollout_body(r_buffer, r_envs)
+            if self.use_hip_graph and key not in self._graphs:
+                try:
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        gstats = self._rollout_body(r_buffer, r_envs)
+                    self._graphs[key] = (graph, gstats)
+                except Exception as e:  # capture is an optimisation only: keep running eagerly
+                    if self.rank == 0:
+                        print("hipGraph capture of the rollout failed (%s); continuing eagerly" % e)
+                    self.use_hip_graph = False
+                    torch.cuda.synchronize()
         self.total_env_steps += self.max_ep_len * r_envs.n_envs * self.world
-        stats = torch.stack([rew_sum, cov_max.double().mean()])
+        stats = stats.clone()
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(stats)
@@ -158,12 +189,13 @@ class Learner:
         self.trainer.prep_rollout()
         E, N = r_buffer.n_rollout_threads, self.n_agents
         obs = r_buffer.obs[cur_step].view(E * N, -1)
-        actions, logp, _ = self.policy.actor(obs)
-        if self.trainer.dedup_critic:
-            values = self.policy.critic(r_buffer.share_obs_env[cur_step])[0].view(E, 1, 1).expand(E, N, 1)
-        else:
-            values = self.policy.critic(r_buffer.share_obs[cur_step].reshape(E * N, -1))[0].view(E, N, 1)
-        return values, actions.view(E, N, -1).contiguous(), logp.view(E, N, 1)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.trainer.amp_bf16):
+            actions, logp, _ = self.policy.actor(obs)
+            if self.trainer.dedup_critic:
+                values = self.policy.critic(r_buffer.share_obs_env[cur_step])[0].view(E, 1, 1).expand(E, N, 1)
+            else:
+                values = self.policy.critic(r_buffer.share_obs[cur_step].reshape(E * N, -1))[0].view(E, N, 1)
+        return values.float(), actions.float().view(E, N, -1).contiguous(), logp.float().view(E, N, 1)
 
     def insert(self, data, r_buffer):
         """masks = 0 where the env finished (learner.py:254-276); obs[t+1] is already in place."""
