@@ -100,6 +100,7 @@ class Learner:
         # hipGraph and replayed (parameters are updated in place, so the graph always sees the current
         # policy).  Measured at config 3: no gain -- the step is bound by the fp32 GEMMs of the policy
         # forward (0.88 ms/step), not by launches -- so it is off by default.
+        self.start_iter, self.cur_iter = 1, 0
         self._graphs = {}
         self.use_hip_graph = bool(self.cfg.use_hip_graph) and ptu.device.type == "cuda"
 
@@ -111,7 +112,8 @@ class Learner:
     # ---- training loop (learner.py:132-175) ---------------------------------------------------------
     def train(self):
         self.warmup(self.rl_buffer, self.train_envs)
-        for iter_ in range(1, self.n_iters + 1):
+        for iter_ in range(self.start_iter, self.n_iters + 1):
+            self.cur_iter = iter_
             if self.use_linear_lr_decay:
                 self.trainer.policy.lr_decay(iter_, self.n_iters)
             rollout_info = self.rollout(self.rl_buffer, self.train_envs)
@@ -234,6 +236,70 @@ class Learner:
 
     def save_model(self, save_path):
         self.trainer.save_model(save_path)
+        self.save_checkpoint(os.path.join(save_path, "resume.pt"))
+
+    # ---- faithful resume ------------------------------------------------------------
+    def save_checkpoint(self, path):
+        """Everything needed to continue a run bit-for-bit: parameters, both Adam states, ValueNorm, the
+        iteration counter, RNG streams and the env state.  (The reference pickles the policy object only:
+        ValueNorm, iteration and RNG are lost, uav_dcc_control/algos/mappo.py:237-247.)"""
+        cpu = lambda d: {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in d.items()}
+        ck = {"format": 1, "iter": self.cur_iter, "total_env_steps": self.total_env_steps,
+              "actor": cpu(self.policy.actor.state_dict()), "critic": cpu(self.policy.critic.state_dict()),
+              "actor_optimizer": self.policy.actor_optimizer.state_dict(),
+              "critic_optimizer": self.policy.critic_optimizer.state_dict(),
+              "value_normalizer": cpu(self.trainer.value_normalizer.state_dict()) if self.trainer.value_normalizer is not None else None,
+              "rng_torch": torch.get_rng_state(), "rng_numpy": np.random.get_state(),
+              "rng_cuda": torch.cuda.get_rng_state(ptu.device) if ptu.device.type == "cuda" else None,
+              "env_state": {k: v.cpu() for k, v in self.train_envs.env.get_state().items()}}
+        torch.save(ck, path)
+
+    def load_checkpoint(self, path):
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.policy.actor.load_state_dict(ck["actor"]); self.policy.critic.load_state_dict(ck["critic"])
+        self.policy.actor_optimizer.load_state_dict(ck["actor_optimizer"])
+        self.policy.critic_optimizer.load_state_dict(ck["critic_optimizer"])
+        if ck["value_normalizer"] is not None and self.trainer.value_normalizer is not None:
+            self.trainer.value_normalizer.load_state_dict(ck["value_normalizer"])
+        torch.set_rng_state(ck["rng_torch"]); np.random.set_state(ck["rng_numpy"])
+        if ck["rng_cuda"] is not None and ptu.device.type == "cuda":
+            torch.cuda.set_rng_state(ck["rng_cuda"], ptu.device)
+        self.train_envs.env.set_state(**ck["env_state"])
+        self.cur_iter, self.start_iter = ck["iter"], ck["iter"] + 1
+        self.total_env_steps = ck["total_env_steps"]
+
+    # ---- headless evaluation (SURVEY.md 8f row 3) ---------------------------------------------------------
+    @torch.no_grad()
+    def evaluate(self, envs=None, steps=None, deterministic=True, dump_path=None):
+        """Roll the current policy without learning and report the metrics of the reference's README curves
+        (coverage rate, steps needed to cover every PoI).  `dump_path` gets the trajectory (positions,
+        PoI energies, rewards, flags per step) as an .npz -- the headless stand-in for the pyglet viewer."""
+        envs = envs if envs is not None else (self.test_envs if self.test_envs is not None else self.train_envs)
+        T = steps or self.max_ep_len
+        E, N = envs.n_envs, self.n_agents
+        self.trainer.prep_rollout()
+        obs = envs.reset_device()
+        rec = {k: [] for k in ("pos", "energy", "reward", "done", "coverage", "connect")}
+        first_done = torch.full((E,), -1, dtype=torch.int32, device=ptu.device)
+        cov_max = torch.zeros(E, device=ptu.device)
+        for t in range(T):
+            actions, _, _ = self.policy.actor(obs.view(E * N, -1), deterministic=deterministic)
+            out = envs.step_device(actions.view(E, N, -1).contiguous())
+            obs = out["obs"]
+            cov_max = torch.maximum(cov_max, out["coverage"])
+            full = (out["coverage"] >= 1.0) & (first_done < 0)
+            first_done = torch.where(full, torch.full_like(first_done, t + 1), first_done)
+            if dump_path is not None:
+                st = envs.env.get_state()
+                rec["pos"].append(st["pos"].cpu()); rec["energy"].append(st["energy"].cpu())
+                for k in ("reward", "done", "coverage", "connect"):
+                    rec[k].append(out[k].cpu())
+        solved = first_done > 0
+        res = {"coverage_rate": float(cov_max.mean()), "solved_fraction": float(solved.float().mean()),
+               "steps_to_cover": float(first_done[solved].float().mean()) if bool(solved.any()) else float("nan")}
+        if dump_path is not None:
+            np.savez_compressed(dump_path, poi=envs.env.poi, **{k: torch.stack(v).numpy() for k, v in rec.items()})
+        return res
 
     def load_model(self, load_path):
         self.trainer.load_model(load_path)
