@@ -170,11 +170,426 @@ struct Stager {
 //
 // NC / MC > 0: N and M are compile-time constants (the BASELINE configs): every loop over agents
 // and PoI tiles unrolls, the staging-window flush points become static and the scalar unit (one per
-// CU, shared by the 16 resident waves) is relieved of loop control and index arithmetic.  NC = 0 is
-// the generic runtime-size kernel.
+// CU, shared by the resident waves) is relieved of loop control and index arithmetic.  NC = 0 is
+// the generic runtime-size code.
+
+constexpr int ACT_R = 2;  // action loads per lane and chunk
+
+// Per-lane registers of one env: lane i < N holds UAV i, lane l holds PoIs {l, l+64, ...}.
+template <int PPL>
+struct EnvRegs {
+    double px, py, vx, vy;
+    float en[PPL];
+    unsigned dmask;  // bit q: PoI q*64+lane is done
+};
+
+// Chunked action prefetch: lane (s*N + i) holds the action of agent i at step (chunk start + s);
+// ACT_R loads per lane -> ACT_R*(64/N) steps per chunk, so that the unavoidable vmcnt wait (which also
+// drains the wave's older stores) is paid once per chunk instead of once per step.
+struct ActFetch {
+    float2 f[ACT_R];
+    double2 d[ACT_R];
+    int kc, r_sel, s_sel;
+};
+
+// PoI coordinates of this lane: registers for <= 4 PoIs per lane, the LDS table otherwise.
+template <int PPL>
+struct PoiLane {
+    static constexpr bool REG = PPL <= 4;
+    static constexpr int NR = REG ? PPL : 1;
+    double x[NR], y[NR];
+    const double2* table;
+    int lane, M;
+    __device__ __forceinline__ void init(const double2* s_poi, int lane_, int M_) {
+        table = s_poi; lane = lane_; M = M_;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int j = q * 64 + lane;
+            x[q] = 0; y[q] = 0;
+            if (REG && j < M) { const double2 pj = s_poi[j]; x[q] = pj.x; y[q] = pj.y; }
+        }
+    }
+    __device__ __forceinline__ double2 get(int q) const {
+        if (REG) return make_double2(x[REG ? q : 0], y[REG ? q : 0]);
+        const int j = q * 64 + lane;
+        return table[j < M ? j : 0];
+    }
+};
+
+// One reference env.step (phases A-F, H, I of SURVEY.md 3.3) of env `env` at fused step `k`.
+// apos_in: UAV positions BEFORE the move (LDS, [N]); apos_out / avel_out: where the post-step (and
+// post-auto-reset) positions / velocities go (may alias apos_in).  Per-step outputs go to HBM.
 template <int PPL, int ACT, bool FORCE, int NC, int MC>
+__device__ __forceinline__ void env_physics_step(const KParams& p, const int env, const int k, const int lane,
+                                                 EnvRegs<PPL>& r, ActFetch& af, const PoiLane<PPL>& poi,
+                                                 const double2* apos_in, double2* apos_out, double2* avel_out) {
+    constexpr bool SPEC = NC > 0;
+    const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
+    constexpr int UNR_F = SPEC ? 4 : 2;  // unroll of the energy-pass loop over agents
+    const size_t ko = (size_t)k * p.E + env;  // index of this env-step in [K,E] outputs
+    const unsigned long long fullN = (N >= 64) ? ~0ULL : ((1ULL << N) - 1ULL);
+
+    // ---- (A) EN:153-201 u = action; u *= 5.0 in the action's dtype ------------------------------
+    float uxf = 0.f, uyf = 0.f;
+    double uxd = 0, uyd = 0;
+    if (ACT == 2) {
+        if (lane < N) {
+            const unsigned long long idx =
+                ((unsigned long long)(p.step0 + (unsigned)k) * (unsigned long long)p.env_total +
+                 (unsigned long long)(p.env0 + env)) * (unsigned long long)N + (unsigned long long)lane;
+            const unsigned long long z = splitmix64(p.seed + 0x9E3779B97F4A7C15ULL * (idx + 1ULL));
+            const unsigned hi = (unsigned)(z >> 40), lo = (unsigned)((z & 0xFFFFFFFFULL) >> 8);
+            uxf = ((float)hi * (1.0f / 8388608.0f) - 1.0f) * p.sens_f;
+            uyf = ((float)lo * (1.0f / 8388608.0f) - 1.0f) * p.sens_f;
+        }
+    } else {
+        const int steps_per_load = 64 / N;  // >= 1 because N <= 64
+        const int chunk = ACT_R * steps_per_load;
+        if (af.kc == chunk) { af.kc = 0; af.r_sel = 0; af.s_sel = 0; }
+        if (af.kc == 0) {
+            const int my_s = SPEC ? (lane / (SPEC ? NC : 1)) : (int)(((unsigned)lane * p.magicN) >> 20);  // lane / N
+            const int my_i = lane - my_s * N;                                                              // lane % N
+#pragma unroll
+            for (int rr = 0; rr < ACT_R; ++rr) {
+                const int ks = k + rr * steps_per_load + my_s;
+                if (my_s < steps_per_load && ks < p.K) {
+                    const size_t ai = ((size_t)ks * p.E + env) * N + my_i;
+                    if (ACT == 1) af.d[rr] = reinterpret_cast<const double2*>(p.actions)[ai];
+                    else af.f[rr] = reinterpret_cast<const float2*>(p.actions)[ai];
+                }
+            }
+            // consume the loads inside this branch: the wait is then paid only on chunk boundaries
+#pragma unroll
+            for (int rr = 0; rr < ACT_R; ++rr) {
+                if (ACT == 1) asm volatile("" : "+v"(af.d[rr].x), "+v"(af.d[rr].y));
+                else asm volatile("" : "+v"(af.f[rr].x), "+v"(af.f[rr].y));
+            }
+        }
+        if (af.s_sel == steps_per_load) { af.s_sel = 0; ++af.r_sel; }
+        const int src = af.s_sel * N + lane;  // lane holding (step kc, agent = lane)
+        ++af.kc; ++af.s_sel;
+        if (ACT == 1) {
+            double2 a = af.d[0];
+#pragma unroll
+            for (int rr = 1; rr < ACT_R; ++rr) if (af.r_sel == rr) a = af.d[rr];
+            const double axd = __shfl(a.x, src & 63, 64), ayd = __shfl(a.y, src & 63, 64);
+            if (lane < N) { uxd = axd * p.sens; uyd = ayd * p.sens; }
+        } else {
+            float2 a = af.f[0];
+#pragma unroll
+            for (int rr = 1; rr < ACT_R; ++rr) if (af.r_sel == rr) a = af.f[rr];
+            const float axf = __shfl(a.x, src & 63, 64), ayf = __shfl(a.y, src & 63, 64);
+            if (lane < N) { uxf = axf * p.sens_f; uyf = ayf * p.sens_f; }
+        }
+    }
+
+    // ---- (B) CW:70-93 update_connect on PRE-move positions --------------------------------------
+    unsigned long long rowA = 0, rowS = 0;  // lane a: adjacency rows (bit b)
+    bool connect = false, connect_s = false;
+    if (p.use_connect) {
+        const int npairs = N * N;
+        for (int r0 = 0; r0 < npairs; r0 += 64) {
+            const int pidx = r0 + lane;
+            const int a = SPEC ? (pidx / (SPEC ? NC : 1)) : (int)(((unsigned)pidx * p.magicN) >> 20);
+            const int b = pidx - a * N;
+            bool adj = false, adjs = false;
+            if (pidx < npairs && a != b) {
+                const double2 pa = apos_in[a], pb = apos_in[b];
+                const double dx = pa.x - pb.x, dy = pa.y - pb.y;
+                const double s = __builtin_fma(dy, dy, dx * dx);
+                adj = s <= p.sq_thr;                 // d < r_a + r_b              (CW:77)
+                adjs = adj && (s <= p.sq_thr_s);     // d < comm_r_scale*(r_a+r_b) (CW:79)
+            }
+            const unsigned long long mA = __ballot(adj), mS = __ballot(adjs);
+            if (lane < N) {
+                const int rs = lane * N;  // first pair index of my row
+                const int lo = rs > r0 ? rs : r0;
+                const int hi = (rs + N) < (r0 + 64) ? (rs + N) : (r0 + 64);
+                if (lo < hi) {
+                    const int w = hi - lo;
+                    const unsigned long long msk = (w >= 64) ? ~0ULL : ((1ULL << w) - 1ULL);
+                    rowA |= ((mA >> (lo - r0)) & msk) << (lo - rs);
+                    rowS |= ((mS >> (lo - r0)) & msk) << (lo - rs);
+                }
+            }
+        }
+        // connect  = all(sum_k A^k > 0)  <=>  graph(A) connected: BFS from node 0 (A symmetric)
+        unsigned long long visited = 1ULL;
+        for (int it = 1; it < N; ++it) {
+            const unsigned long long nv = visited | __ballot(lane < N && (rowA & visited) != 0ULL);
+            if (nv == visited) break;
+            visited = nv;
+        }
+        connect = (visited == fullN);
+        // connect_ = all(I + sum_{k>=1} A^k A_ > 0) (CW:90 multiplies the just-appended A^k):
+        // N=1 -> True; N=2 -> always False; N>=3 -> connected and every node has an A_ neighbour.
+        const unsigned long long iso = __ballot(lane < N && rowS == 0ULL);
+        connect_s = (N == 1) ? true : (N == 2) ? false : (connect && iso == 0ULL);
+
+        // ---- (D) CW:100-140 connectivity-preserving pull force (wave-uniform branch) ----------------
+        if (FORCE && !connect_s) {
+            double best = 0.0, fx = 0.0, fy = 0.0;
+            int bi = 0;
+            const bool branch1 = (iso != 0ULL);
+            const bool mine = (lane < N) && (branch1 ? (rowS == 0ULL) : true);
+            if (mine) {
+                const double2 pa = apos_in[lane];
+                for (int b = 0; b < N; ++b) {
+                    const double2 pb = apos_in[b];
+                    double d = norm2(pa.x - pb.x, pa.y - pb.y);
+                    if (b == lane) d = 1e5;                       // CW:81
+                    else if (!branch1 && d < p.thr2) d = 1e5;     // CW:119-120
+                    if (b == 0 || d < best) { best = d; bi = b; } // np.argmin: first minimum
+                }
+            }
+            unsigned long long todo;
+            if (branch1) {
+                todo = iso;  // CW:110-116: every isolated agent, ascending
+            } else {
+                // CW:121-123: argmin over the flattened matrix = smallest row minimum, lowest row first
+                const double g = wave_min_f64(mine ? best : 1.7976931348623157e308);
+                const unsigned long long eq = __ballot(mine && best == g);
+                todo = 1ULL << __builtin_ctzll(eq);
+            }
+            if (mine && bi != lane && ((todo >> lane) & 1ULL)) {
+                // CW:129-140 get_connect_force(a = me, b = bi)
+                const double2 pa = apos_in[lane], pb = apos_in[bi];
+                const double dx = pa.x - pb.x, dy = pa.y - pb.y;
+                const double dist = norm2(dx, dy);
+                const double pen = logaddexp0((dist - p.dmax) / p.contact_margin) * p.contact_margin;
+                fx = p.contact_force * dx / dist * pen;
+                fy = p.contact_force * dy / dist * pen;
+            }
+            // sequential accumulation in the reference's order (float32 round trip per add when the
+            // action is float32: `p_force[a] += f_a` on a float32 array)
+            while (todo) {
+                const int a = __builtin_ctzll(todo);
+                todo &= todo - 1ULL;
+                const int b = __builtin_amdgcn_readlane(bi, a);
+                const double fax = readlane_f64(fx, a), fay = readlane_f64(fy, a);
+                if (a == b) continue;  // get_connect_force returns [0, 0] (CW:130-131)
+                if (lane == a) {
+                    if (ACT == 1) { uxd += -fax; uyd += -fay; }
+                    else { uxf = (float)((double)uxf + (-fax)); uyf = (float)((double)uyf + (-fay)); }
+                }
+                if (lane == b) {
+                    if (ACT == 1) { uxd += fax; uyd += fay; }
+                    else { uxf = (float)((double)uxf + fax); uyf = (float)((double)uyf + fay); }
+                }
+            }
+        }
+    }
+    wave_fence();  // every read of the pre-move positions is done before they may be overwritten
+
+    // ---- (E) CW:142-155 integrate_state -----------------------------------------------------------
+    if (lane < N) {
+        r.vx = r.vx * p.keep; r.vy = r.vy * p.keep;
+        if (ACT == 1) {
+            r.vx += (uxd / p.mass) * p.dt; r.vy += (uyd / p.mass) * p.dt;
+        } else {
+            float ax = uxf, ay = uyf;
+            if (p.mass_f != 1.0f) { ax = ax / p.mass_f; ay = ay / p.mass_f; }   // x / 1.0f == x exactly
+            ax *= p.dt_f; ay *= p.dt_f;
+            r.vx += (double)ax; r.vy += (double)ay;
+        }
+        const double s2 = r.vx * r.vx + r.vy * r.vy;  // np.square + np.square: no fusion (CW:150)
+        if (s2 > p.sq_speed) {                        // sqrt(s2) > max_speed
+            const double speed = __builtin_sqrt(s2);
+            r.vx = r.vx / speed * p.max_speed; r.vy = r.vy / speed * p.max_speed;
+        }
+        r.px += r.vx * p.dt; r.py += r.vy * p.dt;
+        apos_out[lane] = make_double2(r.px, r.py);
+        avel_out[lane] = make_double2(r.vx, r.vy);
+    }
+    wave_fence();
+
+    // ---- (F) CW:157-174 update_energy + SC:80-97 reward terms on POST-move positions ---------------
+    int n_done = 0, n_just = 0;
+    double part = 0.0;  // per-lane share of (OOB terms - sum of min distances)
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const int j = q * 64 + lane;
+        const bool valid = j < M;
+        const double2 pj = poi.get(q);
+        int cnt = 0, amin = 0;
+        // smin: running minimum of the radicand; sprev: the running minimum just before its last
+        // displacement = the smallest radicand among the agents in front of the argmin.  If sprev is
+        // within a few ulp of smin the rounded distances could tie (np.argmin would then keep the
+        // earlier agent): that case, practically never taken, is resolved exactly below.
+        double smin = 1.7976931348623157e308, sprev = 1.7976931348623157e308;
+#pragma unroll UNR_F
+        for (int i = 0; i < N; ++i) {
+            const double2 xa = apos_out[i];
+            const double dx = pj.x - xa.x, dy = pj.y - xa.y;
+            const double s = __builtin_fma(dy, dy, dx * dx);
+            cnt += (s <= p.sq_cover) ? 1 : 0;  // ||p_j - x_i|| <= r_cover (CW:164-165)
+            const bool lt = s < smin;
+            sprev = lt ? smin : sprev;
+            smin = lt ? s : smin;
+            amin = lt ? i : amin;
+        }
+        const bool near = sprev <= smin * 1.0000000000000009;
+        if (near && p.assign) {  // exact first-minimum on the rounded distances (practically never taken)
+            double dmn = 0.0;
+            for (int i = 0; i < N; ++i) {
+                const double2 xa = apos_out[i];
+                const double d = norm2(pj.x - xa.x, pj.y - xa.y);
+                if (i == 0 || d < dmn) { dmn = d; amin = i; }
+            }
+        }
+        bool dn = (r.dmask >> q) & 1u, just = false;
+        if (valid && !dn) {
+            r.en[q] += (float)cnt;
+            if (r.en[q] >= p.m_energy_f) { dn = true; just = true; r.dmask |= 1u << q; }
+        }
+        n_done += __popcll(__ballot(valid && dn));
+        n_just += __popcll(__ballot(just));
+        if (valid && !dn) part -= __builtin_sqrt(smin);
+        if (valid && p.assign) p.assign[ko * M + j] = (uint8_t)amin;
+    }
+    bool oob = false;
+    if (lane < N) {
+        const double ax = fabs(r.px), ay = fabs(r.py);
+        double s = 0.0;
+        if (ax > p.bound_soft) s += ax - p.bound_soft;
+        if (ay > p.bound_soft) s += ay - p.bound_soft;
+        part += s * p.rew_out;
+        oob = (ax > p.bound_hard) || (ay > p.bound_hard);
+        if (oob) part += p.rew_out;
+    }
+    const bool any_oob = __ballot(oob) != 0ULL;
+    const bool all_done = (n_done == M);
+    double base = wave_sum_f64(part);
+    if (all_done) base += p.rew_done;
+    // EN:106-108 sum over the N per-agent rewards; `just` bonus is paid once (SC:87-89)
+    const double R = (double)N * base + p.rew_cover * (double)n_just;
+    const bool env_done = all_done || any_oob;  // SC:112-117
+    if (lane == 0) {
+        if (p.reward) p.reward[ko] = (float)R;
+        if (p.reward64) p.reward64[ko] = R;
+        if (p.done) p.done[ko] = env_done ? 1 : 0;
+        if (p.connect) p.connect[ko] = connect ? 1 : 0;
+        if (p.connect_s) p.connect_s[ko] = connect_s ? 1 : 0;
+        if (p.coverage) p.coverage[ko] = (float)((double)n_done / (double)M);
+    }
+    // ---- (I) WR:104-109 auto-reset -> SC:64-78 ------------------------------------------------------
+    if (env_done) {
+        r.px = r.py = r.vx = r.vy = 0.0;
+        r.dmask = 0;
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) r.en[q] = 0.f;
+        if (lane < N) { apos_out[lane] = make_double2(0.0, 0.0); avel_out[lane] = make_double2(0.0, 0.0); }
+        wave_fence();
+    }
+}
+
+// ---- (G) SC:99-110 observation rows of one env-step, streamed through the LDS staging window --------
+// apv: flat view [pos | vel][N][2] of the (post-reset) UAV state in LDS; en / dmask: this lane's PoIs.
+template <int PPL, bool FORCE, int NC, int MC>
+__device__ __forceinline__ void produce_obs(const KParams& p, float* gout, float* stg, const double* apv,
+                                            const float (&en)[PPL], const unsigned dmask, const PoiLane<PPL>& poi,
+                                            const int lane) {
+    constexpr bool SPEC = NC > 0;
+    const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
+    const int H = 4 + 2 * (N - 1), D = H + 5 * M, L = N * D;
+    constexpr int UNR_O = SPEC ? ((NC <= 8 && !FORCE) ? NC : 2) : 1;  // full unroll -> static flush points
+    const double2* apos = reinterpret_cast<const double2*>(apv);
+    Stager st;
+    st.stg = stg; st.w0 = 0; st.vec = SPEC ? 1 : p.vec_ok;
+    st.gout = gout;
+#pragma unroll UNR_O
+    for (int i = 0; i < N; ++i) {
+        const double2 xi = apos[i];
+        // header: vel(2) pos(2) (x_k - x_i for k != i); branch-free per lane:
+        //   f<2 -> avel[i][f&1]; f<4 -> apos[i][f&1]; else apos[k'][f&1] - x_i[f&1], k' skips i
+        for (int f0 = 0; f0 < H; f0 += 64) {
+            const int len = (H - f0) < 64 ? (H - f0) : 64;
+            float* dst = st.reserve(i * D + f0, len, lane);
+            const int f = f0 + lane;
+            if (f < H) {
+                const int c = f & 1;
+                const int kk = (f - 4) >> 1;
+                const bool rel = f >= 4;
+                const int src = rel ? (kk + (kk >= i ? 1 : 0)) : (f < 2 ? N + i : i);
+                const double val = apv[2 * src + c];
+                const double sub = rel ? (c ? xi.y : xi.x) : 0.0;
+                dst[lane] = (float)(val - sub);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            if (q * 64 < M) {
+                const int cntj = (M - q * 64) < 64 ? (M - q * 64) : 64;
+                float* dst = st.reserve(i * D + H + q * kTileFloats, 5 * cntj, lane);
+                if (lane < cntj) {
+                    float* d5 = dst + 5 * lane;
+                    const double2 pj = poi.get(q);
+                    d5[0] = (float)(pj.x - xi.x);
+                    d5[1] = (float)(pj.y - xi.y);
+                    d5[2] = en[q];
+                    d5[3] = p.m_energy_f;
+                    d5[4] = ((dmask >> q) & 1u) ? 1.f : 0.f;
+                }
+            }
+        }
+    }
+    st.flush(L, lane);
+}
+
+template <int PPL>
+__device__ __forceinline__ void load_env_state(const KParams& p, int env, int lane, int N, int M, EnvRegs<PPL>& r) {
+    r.px = r.py = r.vx = r.vy = 0.0;
+    r.dmask = 0;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) r.en[q] = 0.f;
+    if (p.mode == 0) {
+        if (lane < N) {
+            const double2 a = p.pos[(size_t)env * N + lane], b = p.vel[(size_t)env * N + lane];
+            r.px = a.x; r.py = a.y; r.vx = b.x; r.vy = b.y;
+        }
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            const int j = q * 64 + lane;
+            if (j < M) {
+                r.en[q] = p.energy[(size_t)env * M + j];
+                if (p.done_poi[(size_t)env * M + j]) r.dmask |= 1u << q;
+            }
+        }
+    }
+    // Every value loaded from HBM is consumed here, once: the step loop then contains no use of a
+    // pending load, so the compiler never has to drain the obs stores (s_waitcnt vmcnt(0)) of earlier
+    // steps in the middle of a step.
+    asm volatile("" : "+v"(r.px), "+v"(r.py), "+v"(r.vx), "+v"(r.vy), "+v"(r.dmask));
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) asm volatile("" : "+v"(r.en[q]));
+}
+
+template <int PPL>
+__device__ __forceinline__ void store_env_state(const KParams& p, int env, int lane, int N, int M, const EnvRegs<PPL>& r) {
+    if (lane < N) {
+        p.pos[(size_t)env * N + lane] = make_double2(r.px, r.py);
+        p.vel[(size_t)env * N + lane] = make_double2(r.vx, r.vy);
+    }
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const int j = q * 64 + lane;
+        if (j < M) {
+            p.energy[(size_t)env * M + j] = r.en[q];
+            p.done_poi[(size_t)env * M + j] = (r.dmask >> q) & 1u;
+        }
+    }
+}
+
+__device__ __forceinline__ void init_act(ActFetch& af) {
+#pragma unroll
+    for (int rr = 0; rr < ACT_R; ++rr) { af.f[rr] = make_float2(0.f, 0.f); af.d[rr] = make_double2(0.0, 0.0); }
+    af.kc = 0; af.r_sel = 0; af.s_sel = 0;
+}
+
+// ---- kernel 1: fused -- one env per wavefront does physics AND its own observation stores ------------
 // Register budget: 4 waves/SIMD (<=128 VGPRs) keeps all 1024 workgroups of a 4096-env batch co-resident;
 // kernels that hold >= 8 PoIs per lane or the pull-force path trade occupancy for registers instead of spilling.
+template <int PPL, int ACT, bool FORCE, int NC, int MC>
 __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? 3 : 4))) void dcc_env_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -182,9 +597,7 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? 3 : 4))) void dcc_
     const int env = blockIdx.x * kWavesPerBlock + wid;
     constexpr bool SPEC = NC > 0;
     const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
-    const int H = 4 + 2 * (N - 1), D = H + 5 * M, L = N * D;
-    constexpr int UNR_F = SPEC ? 4 : 2;                    // unroll of the energy-pass loop over agents
-    constexpr int UNR_O = SPEC ? ((NC <= 8 && !FORCE) ? NC : 2) : 1;   // unroll of the observation-row loop (static flush points when full)
+    const int L = N * (4 + 2 * (N - 1) + 5 * M);
 
     // LDS carve: PoI table shared by the block, then per wave: apos[N], avel[N], staging[C].
     double2* s_poi = reinterpret_cast<double2*>(smem);
@@ -192,383 +605,143 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? 3 : 4))) void dcc_
     unsigned char* wbase = smem + ((M * 16 + 15) & ~15) + wid * per_wave;
     double2* apos = reinterpret_cast<double2*>(wbase);
     double2* avel = apos + N;
-    const double* apv = reinterpret_cast<const double*>(wbase);  // flat view: [pos | vel][N][2]
     float* stg = reinterpret_cast<float*>(avel + N);
 
     for (int j = threadIdx.x; j < M; j += kBlock) s_poi[j] = p.poi[j];
     __syncthreads();
     if (env >= p.E) return;
 
-    // ---- load state -------------------------------------------------------------------------
-    double px = 0, py = 0, vx = 0, vy = 0;
-    float en[PPL];
-    unsigned dmask = 0;  // bit q: PoI q*64+lane is done
-    // PoI coordinates: in registers for <= 4 PoIs per lane, re-read from the LDS table otherwise
-    constexpr bool PJ_REG = PPL <= 4;
-    constexpr int NPJ = PJ_REG ? PPL : 1;
-    double pjx_r[NPJ], pjy_r[NPJ];
-#pragma unroll
-    for (int q = 0; q < PPL; ++q) en[q] = 0.f;
-#pragma unroll
-    for (int q = 0; q < NPJ; ++q) {
-        const int j = q * 64 + lane;
-        pjx_r[q] = 0; pjy_r[q] = 0;
-        if (PJ_REG && j < M) { const double2 pj = s_poi[j]; pjx_r[q] = pj.x; pjy_r[q] = pj.y; }
-    }
-    auto poi_of = [&](int q) -> double2 {
-        if (PJ_REG) return make_double2(pjx_r[PJ_REG ? q : 0], pjy_r[PJ_REG ? q : 0]);
-        const int j = q * 64 + lane;
-        return s_poi[j < M ? j : 0];
-    };
-    if (p.mode == 0) {
-        if (lane < N) {
-            const double2 a = p.pos[(size_t)env * N + lane], b = p.vel[(size_t)env * N + lane];
-            px = a.x; py = a.y; vx = b.x; vy = b.y;
-        }
-#pragma unroll
-        for (int q = 0; q < PPL; ++q) {
-            const int j = q * 64 + lane;
-            if (j < M) {
-                en[q] = p.energy[(size_t)env * M + j];
-                if (p.done_poi[(size_t)env * M + j]) dmask |= 1u << q;
-            }
-        }
-    }
-    if (lane < N) { apos[lane] = make_double2(px, py); avel[lane] = make_double2(vx, vy); }
+    EnvRegs<PPL> r;
+    PoiLane<PPL> poi;
+    poi.init(s_poi, lane, M);
+    load_env_state<PPL>(p, env, lane, N, M, r);
+    if (lane < N) { apos[lane] = make_double2(r.px, r.py); avel[lane] = make_double2(r.vx, r.vy); }
     wave_fence();
-    // Every value loaded from HBM above is consumed here, once: the step loop then contains no
-    // use of a pending load, so the compiler never has to drain the obs stores (s_waitcnt vmcnt(0))
-    // of earlier steps in the middle of a step.
-    asm volatile("" : "+v"(px), "+v"(py), "+v"(vx), "+v"(vy), "+v"(dmask));
-#pragma unroll
-    for (int q = 0; q < PPL; ++q) asm volatile("" : "+v"(en[q]));
-
-    // Actions from HBM are fetched for a whole chunk of steps at once: lane (s*N + i) holds the
-    // action of agent i at step (chunk start + s); ACT_R loads per lane -> ACT_R*(64/N) steps per
-    // chunk, so that the unavoidable vmcnt wait (which also drains this wave's older obs stores)
-    // is paid once per chunk instead of once per step.
-    constexpr int ACT_R = 2;
-    const int steps_per_load = 64 / N;                 // >= 1 because N <= 64
-    const int chunk = ACT_R * steps_per_load;
-    const int my_s = SPEC ? (lane / (SPEC ? NC : 1)) : (int)(((unsigned)lane * p.magicN) >> 20);   // lane / N
-    const int my_i = lane - my_s * N;                            // lane % N
-    float2 abuf_f[ACT_R];
-    double2 abuf_d[ACT_R];
-#pragma unroll
-    for (int r = 0; r < ACT_R; ++r) { abuf_f[r] = make_float2(0.f, 0.f); abuf_d[r] = make_double2(0.0, 0.0); }
-
-    const unsigned long long fullN = (N >= 64) ? ~0ULL : ((1ULL << N) - 1ULL);
-    int kc = 0, r_sel = 0, s_sel = 0;  // position inside the current action chunk
+    ActFetch af;
+    init_act(af);
 
     for (int k = 0; k < p.K; ++k) {
-        const size_t ko = (size_t)k * p.E + env;  // index of this env-step in [K,E] outputs
-        if (p.mode == 0) {
-            // ---- (A) EN:153-201 u = action; u *= 5.0 in the action's dtype ------------------
-            float uxf = 0.f, uyf = 0.f;
-            double uxd = 0, uyd = 0;
-            if (ACT == 2) {
-                if (lane < N) {
-                    const unsigned long long idx =
-                        ((unsigned long long)(p.step0 + (unsigned)k) * (unsigned long long)p.env_total +
-                         (unsigned long long)(p.env0 + env)) * (unsigned long long)N + (unsigned long long)lane;
-                    const unsigned long long z = splitmix64(p.seed + 0x9E3779B97F4A7C15ULL * (idx + 1ULL));
-                    const unsigned hi = (unsigned)(z >> 40), lo = (unsigned)((z & 0xFFFFFFFFULL) >> 8);
-                    uxf = ((float)hi * (1.0f / 8388608.0f) - 1.0f) * p.sens_f;
-                    uyf = ((float)lo * (1.0f / 8388608.0f) - 1.0f) * p.sens_f;
-                }
-            } else {
-                if (kc == chunk) { kc = 0; r_sel = 0; s_sel = 0; }
-                if (kc == 0) {
-#pragma unroll
-                    for (int r = 0; r < ACT_R; ++r) {
-                        const int ks = k + r * steps_per_load + my_s;
-                        if (my_s < steps_per_load && ks < p.K) {
-                            const size_t ai = ((size_t)ks * p.E + env) * N + my_i;
-                            if (ACT == 1) abuf_d[r] = reinterpret_cast<const double2*>(p.actions)[ai];
-                            else abuf_f[r] = reinterpret_cast<const float2*>(p.actions)[ai];
-                        }
-                    }
-                    // consume the loads inside this branch: the wait (which also drains this wave's
-                    // older stores) is then paid only on chunk boundaries
-#pragma unroll
-                    for (int r = 0; r < ACT_R; ++r) {
-                        if (ACT == 1) asm volatile("" : "+v"(abuf_d[r].x), "+v"(abuf_d[r].y));
-                        else asm volatile("" : "+v"(abuf_f[r].x), "+v"(abuf_f[r].y));
-                    }
-                }
-                if (s_sel == steps_per_load) { s_sel = 0; ++r_sel; }
-                const int src = s_sel * N + lane;  // lane holding (step kc, agent = lane)
-                ++kc; ++s_sel;
-                if (ACT == 1) {
-                    double2 a = abuf_d[0];
-#pragma unroll
-                    for (int r = 1; r < ACT_R; ++r) if (r_sel == r) a = abuf_d[r];
-                    const double axd = __shfl(a.x, src & 63, 64), ayd = __shfl(a.y, src & 63, 64);
-                    if (lane < N) { uxd = axd * p.sens; uyd = ayd * p.sens; }
-                } else {
-                    float2 a = abuf_f[0];
-#pragma unroll
-                    for (int r = 1; r < ACT_R; ++r) if (r_sel == r) a = abuf_f[r];
-                    const float axf = __shfl(a.x, src & 63, 64), ayf = __shfl(a.y, src & 63, 64);
-                    if (lane < N) { uxf = axf * p.sens_f; uyf = ayf * p.sens_f; }
-                }
-            }
+        if (p.mode == 0) env_physics_step<PPL, ACT, FORCE, NC, MC>(p, env, k, lane, r, af, poi, apos, apos, avel);
+        if (p.obs)
+            produce_obs<PPL, FORCE, NC, MC>(p, p.obs + ((size_t)k * p.E + env) * (size_t)L, stg,
+                                            reinterpret_cast<const double*>(apos), r.en, r.dmask, poi, lane);
+    }
+    store_env_state<PPL>(p, env, lane, N, M, r);
+}
 
-            // ---- (B) CW:70-93 update_connect on PRE-move positions --------------------------
-            unsigned long long rowA = 0, rowS = 0;  // lane a: adjacency rows (bit b)
-            bool connect = false, connect_s = false;
-            if (p.use_connect) {
-                const int npairs = N * N;
-                for (int r0 = 0; r0 < npairs; r0 += 64) {
-                    const int pidx = r0 + lane;
-                    const int a = SPEC ? (pidx / (SPEC ? NC : 1)) : (int)(((unsigned)pidx * p.magicN) >> 20);
-                    const int b = pidx - a * N;
-                    bool adj = false, adjs = false;
-                    if (pidx < npairs && a != b) {
-                        const double2 pa = apos[a], pb = apos[b];
-                        const double dx = pa.x - pb.x, dy = pa.y - pb.y;
-                        const double s = __builtin_fma(dy, dy, dx * dx);
-                        adj = s <= p.sq_thr;                 // d < r_a + r_b            (CW:77)
-                        adjs = adj && (s <= p.sq_thr_s);     // d < comm_r_scale*(r_a+r_b) (CW:79)
-                    }
-                    const unsigned long long mA = __ballot(adj), mS = __ballot(adjs);
-                    if (lane < N) {
-                        const int rs = lane * N;  // first pair index of my row
-                        const int lo = rs > r0 ? rs : r0;
-                        const int hi = (rs + N) < (r0 + 64) ? (rs + N) : (r0 + 64);
-                        if (lo < hi) {
-                            const int w = hi - lo;
-                            const unsigned long long msk = (w >= 64) ? ~0ULL : ((1ULL << w) - 1ULL);
-                            rowA |= ((mA >> (lo - r0)) & msk) << (lo - rs);
-                            rowS |= ((mS >> (lo - r0)) & msk) << (lo - rs);
-                        }
-                    }
-                }
-                // connect  = all(sum_k A^k > 0)  <=>  graph(A) connected: BFS from node 0 (A symmetric)
-                unsigned long long visited = 1ULL;
-                for (int it = 1; it < N; ++it) {
-                    const unsigned long long nv = visited | __ballot(lane < N && (rowA & visited) != 0ULL);
-                    if (nv == visited) break;
-                    visited = nv;
-                }
-                connect = (visited == fullN);
-                // connect_ = all(I + sum_{k>=1} A^k A_ > 0) (CW:90 multiplies the just-appended A^k):
-                // N=1 -> True; N=2 -> always False; N>=3 -> connected and every node has an A_ neighbour.
-                const unsigned long long iso = __ballot(lane < N && rowS == 0ULL);
-                connect_s = (N == 1) ? true : (N == 2) ? false : (connect && iso == 0ULL);
+// ---- kernel 2: role-specialised -- a PHYSICS wave and an OBSERVATION wave per workgroup --------------------
+// Measured on MI355X (tools/overlap_probe*.hip): when every wave alternates compute and its 10.8 KB of obs
+// stores, the compute overlaps only ~2/3 with the chip-wide store stream; waves that do nothing but stream
+// stores keep HBM saturated while other waves compute in their shadow.  Here a workgroup is two waves serving
+// two envs: wave 0 runs the physics of both envs and hands the post-step state (positions, velocities, PoI
+// energies, done mask: ~0.5 KB) to wave 1 through a double-buffered LDS slot; wave 1 expands it into the
+// observation rows and streams them to HBM.  ready/consumed counters in LDS (workgroup-scope release/acquire)
+// let the physics wave run up to two steps ahead, so the observation wave always has a backlog.
+constexpr int kRolesBlock = 128;
+struct Handoff {  // one env, one slot; laid out in LDS as: apos[N] | avel[N] | en[64] | dmask(u64) | pad
+    double2* apos; double2* avel; float* en; unsigned long long* dmask;
+};
+__device__ __forceinline__ Handoff handoff_at(unsigned char* base, int N) {
+    Handoff h;
+    h.apos = reinterpret_cast<double2*>(base);
+    h.avel = h.apos + N;
+    h.en = reinterpret_cast<float*>(h.avel + N);
+    h.dmask = reinterpret_cast<unsigned long long*>(h.en + 64);
+    return h;
+}
+__device__ __forceinline__ int handoff_bytes(int N) { return N * 32 + 64 * 4 + 16; }
 
-                // ---- (D) CW:100-140 connectivity-preserving pull force (wave-uniform branch) ----
-                if (FORCE && !connect_s) {
-                    double best = 0.0, fx = 0.0, fy = 0.0;
-                    int bi = 0;
-                    const bool branch1 = (iso != 0ULL);
-                    const bool mine = (lane < N) && (branch1 ? (rowS == 0ULL) : true);
-                    if (mine) {
-                        const double2 pa = apos[lane];
-                        for (int b = 0; b < N; ++b) {
-                            const double2 pb = apos[b];
-                            double d = norm2(pa.x - pb.x, pa.y - pb.y);
-                            if (b == lane) d = 1e5;                       // CW:81
-                            else if (!branch1 && d < p.thr2) d = 1e5;     // CW:119-120
-                            if (b == 0 || d < best) { best = d; bi = b; } // np.argmin: first minimum
-                        }
-                    }
-                    unsigned long long todo;
-                    if (branch1) {
-                        todo = iso;  // CW:110-116: every isolated agent, ascending
-                    } else {
-                        // CW:121-123: argmin over the flattened matrix = smallest row minimum, lowest row first
-                        const double g = wave_min_f64(mine ? best : 1.7976931348623157e308);
-                        const unsigned long long eq = __ballot(mine && best == g);
-                        todo = 1ULL << __builtin_ctzll(eq);
-                    }
-                    if (mine && bi != lane && ((todo >> lane) & 1ULL)) {
-                        // CW:129-140 get_connect_force(a = me, b = bi)
-                        const double2 pa = apos[lane], pb = apos[bi];
-                        const double dx = pa.x - pb.x, dy = pa.y - pb.y;
-                        const double dist = norm2(dx, dy);
-                        const double pen = logaddexp0((dist - p.dmax) / p.contact_margin) * p.contact_margin;
-                        fx = p.contact_force * dx / dist * pen;
-                        fy = p.contact_force * dy / dist * pen;
-                    }
-                    // sequential accumulation in the reference's order (float32 round trip per add
-                    // when the action is float32: `p_force[a] += f_a` on a float32 array)
-                    while (todo) {
-                        const int a = __builtin_ctzll(todo);
-                        todo &= todo - 1ULL;
-                        const int b = __builtin_amdgcn_readlane(bi, a);
-                        const double fax = readlane_f64(fx, a), fay = readlane_f64(fy, a);
-                        if (a == b) continue;  // get_connect_force returns [0, 0] (CW:130-131)
-                        if (lane == a) {
-                            if (ACT == 1) { uxd += -fax; uyd += -fay; }
-                            else { uxf = (float)((double)uxf + (-fax)); uyf = (float)((double)uyf + (-fay)); }
-                        }
-                        if (lane == b) {
-                            if (ACT == 1) { uxd += fax; uyd += fay; }
-                            else { uxf = (float)((double)uxf + fax); uyf = (float)((double)uyf + fay); }
-                        }
-                    }
-                }
-            }
+__device__ __forceinline__ void spin_until_ge(unsigned* flag, unsigned v) {
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(2);
+}
+__device__ __forceinline__ void publish(unsigned* flag, unsigned v, int lane) {
+    wave_fence();
+    if (lane == 0) __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
-            // ---- (E) CW:142-155 integrate_state ----------------------------------------------
-            if (lane < N) {
-                vx = vx * p.keep; vy = vy * p.keep;
-                if (ACT == 1) {
-                    vx += (uxd / p.mass) * p.dt; vy += (uyd / p.mass) * p.dt;
-                } else {
-                    float ax = uxf, ay = uyf;
-                    if (p.mass_f != 1.0f) { ax = ax / p.mass_f; ay = ay / p.mass_f; }   // x / 1.0f == x exactly
-                    ax *= p.dt_f; ay *= p.dt_f;
-                    vx += (double)ax; vy += (double)ay;
-                }
-                const double s2 = vx * vx + vy * vy;      // np.square + np.square: no fusion (CW:150)
-                if (s2 > p.sq_speed) {                    // sqrt(s2) > max_speed
-                    const double speed = __builtin_sqrt(s2);
-                    vx = vx / speed * p.max_speed; vy = vy / speed * p.max_speed;
-                }
-                px += vx * p.dt; py += vy * p.dt;
-                apos[lane] = make_double2(px, py);
-                avel[lane] = make_double2(vx, vy);
-            }
-            wave_fence();
+template <int ACT, bool FORCE, int NC, int MC>
+__global__ __launch_bounds__(kRolesBlock, 2) void dcc_env_roles_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int PPL = 1;
+    constexpr bool SPEC = NC > 0;
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 = physics, 1 = observation
+    const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
+    const int L = N * (4 + 2 * (N - 1) + 5 * M);
+    const int env_base = blockIdx.x * 2;
 
-            // ---- (F) CW:157-174 update_energy + SC:80-97 reward terms on POST-move positions ---
-            int n_done = 0, n_just = 0;
-            double part = 0.0;  // per-lane share of (OOB terms - sum of min distances)
+    // LDS: PoI table | hand-off [env 0..1][slot 0..1] | flags ready[2], consumed[2] | staging window
+    double2* s_poi = reinterpret_cast<double2*>(smem);
+    const int hb = handoff_bytes(N);
+    unsigned char* hbase = smem + ((M * 16 + 15) & ~15);
+    unsigned* flags = reinterpret_cast<unsigned*>(hbase + 4 * hb);
+    float* stg = reinterpret_cast<float*>(hbase + 4 * hb + 16);
+
+    for (int j = threadIdx.x; j < M; j += kRolesBlock) s_poi[j] = p.poi[j];
+    if (threadIdx.x < 4) flags[threadIdx.x] = 0u;
+    __syncthreads();
+
+    PoiLane<PPL> poi;
+    poi.init(s_poi, lane, M);
+
+    if (role == 0) {
+        // ---------------- physics wave: both envs of the workgroup, up to two steps ahead -------------------
+        EnvRegs<PPL> r[2];
+        ActFetch af[2];
 #pragma unroll
-            for (int q = 0; q < PPL; ++q) {
-                const int j = q * 64 + lane;
-                const bool valid = j < M;
-                const double2 pj = poi_of(q);
-                int cnt = 0, amin = 0;
-                // smin: running minimum of the radicand; sprev: the running minimum just before its last
-                // displacement = the smallest radicand among the agents in front of the argmin.  If sprev is
-                // within a few ulp of smin the rounded distances could tie (np.argmin would then keep the
-                // earlier agent): that case, practically never taken, is resolved exactly below.
-                double smin = 1.7976931348623157e308, sprev = 1.7976931348623157e308;
-#pragma unroll UNR_F
-                for (int i = 0; i < N; ++i) {
-                    const double2 xa = apos[i];
-                    const double dx = pj.x - xa.x, dy = pj.y - xa.y;
-                    const double s = __builtin_fma(dy, dy, dx * dx);
-                    cnt += (s <= p.sq_cover) ? 1 : 0;      // ||p_j - x_i|| <= r_cover (CW:164-165)
-                    const bool lt = s < smin;
-                    sprev = lt ? smin : sprev;
-                    smin = lt ? s : smin;
-                    amin = lt ? i : amin;
-                }
-                const bool near = sprev <= smin * 1.0000000000000009;
-                if (near && p.assign) {  // exact first-minimum on the rounded distances (practically never taken)
-                    double dmn = 0.0;
-                    for (int i = 0; i < N; ++i) {
-                        const double2 xa = apos[i];
-                        const double d = norm2(pj.x - xa.x, pj.y - xa.y);
-                        if (i == 0 || d < dmn) { dmn = d; amin = i; }
-                    }
-                }
-                bool dn = (dmask >> q) & 1u, just = false;
-                if (valid && !dn) {
-                    en[q] += (float)cnt;
-                    if (en[q] >= p.m_energy_f) { dn = true; just = true; dmask |= 1u << q; }
-                }
-                n_done += __popcll(__ballot(valid && dn));
-                n_just += __popcll(__ballot(just));
-                if (valid && !dn) part -= __builtin_sqrt(smin);
-                if (valid && p.assign) p.assign[ko * M + j] = (uint8_t)amin;
-            }
-            bool oob = false;
-            if (lane < N) {
-                const double ax = fabs(px), ay = fabs(py);
-                double s = 0.0;
-                if (ax > p.bound_soft) s += ax - p.bound_soft;
-                if (ay > p.bound_soft) s += ay - p.bound_soft;
-                part += s * p.rew_out;
-                oob = (ax > p.bound_hard) || (ay > p.bound_hard);
-                if (oob) part += p.rew_out;
-            }
-            const bool any_oob = __ballot(oob) != 0ULL;
-            const bool all_done = (n_done == M);
-            double base = wave_sum_f64(part);
-            if (all_done) base += p.rew_done;
-            // EN:106-108 sum over the N per-agent rewards; `just` bonus is paid once (SC:87-89)
-            const double R = (double)N * base + p.rew_cover * (double)n_just;
-            const bool env_done = all_done || any_oob;  // SC:112-117
-            if (lane == 0) {
-                if (p.reward) p.reward[ko] = (float)R;
-                if (p.reward64) p.reward64[ko] = R;
-                if (p.done) p.done[ko] = env_done ? 1 : 0;
-                if (p.connect) p.connect[ko] = connect ? 1 : 0;
-                if (p.connect_s) p.connect_s[ko] = connect_s ? 1 : 0;
-                if (p.coverage) p.coverage[ko] = (float)((double)n_done / (double)M);
-            }
-            // ---- (I) WR:104-109 auto-reset -> SC:64-78 -----------------------------------------
-            if (env_done) {
-                px = py = vx = vy = 0.0;
-                dmask = 0;
-#pragma unroll
-                for (int q = 0; q < PPL; ++q) en[q] = 0.f;
-                if (lane < N) { apos[lane] = make_double2(0.0, 0.0); avel[lane] = make_double2(0.0, 0.0); }
-                wave_fence();
+        for (int s = 0; s < 2; ++s) {
+            const int env = env_base + s;
+            init_act(af[s]);
+            if (env < p.E) {
+                load_env_state<PPL>(p, env, lane, N, M, r[s]);
+                // the "previous" slot (1) holds the pre-move positions of step 0
+                Handoff h = handoff_at(hbase + (2 * s + 1) * hb, N);
+                if (lane < N) { h.apos[lane] = make_double2(r[s].px, r[s].py); h.avel[lane] = make_double2(r[s].vx, r[s].vy); }
             }
         }
-
-        // ---- (G) SC:99-110 observation rows, streamed through the LDS staging window ----------
-        if (p.obs) {
-            Stager st;
-            st.stg = stg; st.w0 = 0; st.vec = SPEC ? 1 : p.vec_ok;
-            st.gout = p.obs + ko * (size_t)L;
-#pragma unroll UNR_O
-            for (int i = 0; i < N; ++i) {
-                const double2 xi = apos[i];
-                // header: vel(2) pos(2) (x_k - x_i for k != i); branch-free per lane:
-                //   f<2 -> avel[i][f&1]; f<4 -> apos[i][f&1]; else apos[k'][f&1] - x_i[f&1], k' skips i
-                for (int f0 = 0; f0 < H; f0 += 64) {
-                    const int len = (H - f0) < 64 ? (H - f0) : 64;
-                    float* dst = st.reserve(i * D + f0, len, lane);
-                    const int f = f0 + lane;
-                    if (f < H) {
-                        const int c = f & 1;
-                        const int kk = (f - 4) >> 1;
-                        const bool rel = f >= 4;
-                        const int src = rel ? (kk + (kk >= i ? 1 : 0)) : (f < 2 ? N + i : i);
-                        const double val = apv[2 * src + c];
-                        const double sub = rel ? (c ? xi.y : xi.x) : 0.0;
-                        dst[lane] = (float)(val - sub);
-                    }
-                }
+        wave_fence();
+        for (int k = 0; k < p.K; ++k) {
 #pragma unroll
-                for (int q = 0; q < PPL; ++q) {
-                    if (q * 64 < M) {
-                        const int cntj = (M - q * 64) < 64 ? (M - q * 64) : 64;
-                        float* dst = st.reserve(i * D + H + q * kTileFloats, 5 * cntj, lane);
-                        if (lane < cntj) {
-                            float* d5 = dst + 5 * lane;
-                            const double2 pj = poi_of(q);
-                            d5[0] = (float)(pj.x - xi.x);
-                            d5[1] = (float)(pj.y - xi.y);
-                            d5[2] = en[q];
-                            d5[3] = p.m_energy_f;
-                            d5[4] = ((dmask >> q) & 1u) ? 1.f : 0.f;
-                        }
-                    }
+            for (int s = 0; s < 2; ++s) {
+                const int env = env_base + s;
+                if (env >= p.E) continue;
+                const int slot = k & 1;
+                Handoff out = handoff_at(hbase + (2 * s + slot) * hb, N);
+                Handoff in = handoff_at(hbase + (2 * s + (slot ^ 1)) * hb, N);
+                // slot `slot` was published at step k-2: wait until the observation wave has read it
+                if (k >= 2) spin_until_ge(&flags[2 + s], (unsigned)(k - 1));
+                if (p.mode == 0) {
+                    env_physics_step<PPL, ACT, FORCE, NC, MC>(p, env, k, lane, r[s], af[s], poi, in.apos, out.apos, out.avel);
+                } else if (lane < N) {
+                    out.apos[lane] = make_double2(r[s].px, r[s].py); out.avel[lane] = make_double2(r[s].vx, r[s].vy);
                 }
+                out.en[lane] = r[s].en[0];
+                const unsigned long long dm = __ballot((r[s].dmask & 1u) != 0u);
+                if (lane == 0) *out.dmask = dm;
+                publish(&flags[s], (unsigned)(k + 1), lane);
             }
-            st.flush(L, lane);
         }
-    }
-
-    // ---- store state ------------------------------------------------------------------------------
-    if (lane < N) {
-        p.pos[(size_t)env * N + lane] = make_double2(px, py);
-        p.vel[(size_t)env * N + lane] = make_double2(vx, vy);
-    }
 #pragma unroll
-    for (int q = 0; q < PPL; ++q) {
-        const int j = q * 64 + lane;
-        if (j < M) {
-            p.energy[(size_t)env * M + j] = en[q];
-            p.done_poi[(size_t)env * M + j] = (dmask >> q) & 1u;
+        for (int s = 0; s < 2; ++s)
+            if (env_base + s < p.E) store_env_state<PPL>(p, env_base + s, lane, N, M, r[s]);
+    } else {
+        // ---------------- observation wave: expand + stream, one env-step at a time ---------------------------
+        // It is the wave that feeds HBM: it outranks the physics waves on its SIMD (they have slack).
+        __builtin_amdgcn_s_setprio(3);
+        for (int k = 0; k < p.K; ++k) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int env = env_base + s;
+                if (env >= p.E) continue;
+                spin_until_ge(&flags[s], (unsigned)(k + 1));
+                Handoff h = handoff_at(hbase + (2 * s + (k & 1)) * hb, N);
+                float en[1];
+                en[0] = h.en[lane];
+                const unsigned dmask = (unsigned)((*h.dmask >> lane) & 1ULL);
+                produce_obs<PPL, FORCE, NC, MC>(p, p.obs + ((size_t)k * p.E + env) * (size_t)L, stg,
+                                                reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane);
+                publish(&flags[2 + s], (unsigned)(k + 1), lane);
+            }
         }
     }
 }
@@ -601,8 +774,8 @@ struct dcc_env {
     double2* d_vel = nullptr;
     float* d_energy = nullptr;
     uint8_t* d_done = nullptr;
-    size_t lds_bytes = 0;
-    bool no_spec = false;
+    size_t lds_bytes = 0, lds_bytes_roles = 0;
+    bool no_spec = false, no_roles = false;
 };
 
 namespace {
@@ -643,13 +816,40 @@ kernel_fn pick_kernel(int ppl, int act, bool force, int n, int m, bool allow_spe
     return act == 0 ? pick_ppl<0, false>(ppl) : act == 1 ? pick_ppl<1, false>(ppl) : pick_ppl<2, false>(ppl);
 }
 
+// role-specialised kernels (one PoI per lane only): generic size + the small BASELINE configs
+template <int ACT, bool FORCE>
+kernel_fn pick_roles(int n, int m, bool allow_spec) {
+    if (allow_spec) {
+        if (n == 8 && m == 64) return dcc_env_roles_kernel<ACT, FORCE, 8, 64>;
+        if (n == 4 && m == 16) return dcc_env_roles_kernel<ACT, FORCE, 4, 16>;
+        if (n == 4 && m == 20) return dcc_env_roles_kernel<ACT, FORCE, 4, 20>;
+    }
+    return dcc_env_roles_kernel<ACT, FORCE, 0, 0>;
+}
+
+kernel_fn pick_roles_kernel(int act, bool force, int n, int m, bool allow_spec) {
+    if (force) return act == 0 ? pick_roles<0, true>(n, m, allow_spec) : act == 1 ? pick_roles<1, true>(n, m, allow_spec)
+                                                                                  : pick_roles<2, true>(n, m, allow_spec);
+    return act == 0 ? pick_roles<0, false>(n, m, allow_spec) : act == 1 ? pick_roles<1, false>(n, m, allow_spec)
+                                                                          : pick_roles<2, false>(n, m, allow_spec);
+}
+
 // act: 0 = f32 actions, 1 = f64 actions, 2 = in-kernel generator
 int launch(dcc_env* env, KParams& p, int act, void* stream) {
-    // specialised kernels assume float4-aligned obs rows; DCC_NO_SPEC=1 forces the generic kernel (tests)
+    // specialised kernels assume float4-aligned obs rows; DCC_NO_SPEC=1 forces the generic kernels (tests)
     const bool allow_spec = (p.obs == nullptr || p.vec_ok) && !env->no_spec;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // observation-producing launches with one PoI per lane use the role-specialised kernel
+    // (DCC_NO_ROLES=1 forces the fused kernel: tests, A/B)
+    if (p.obs != nullptr && env->PPL == 1 && !env->no_roles) {
+        kernel_fn fn = pick_roles_kernel(act, p.use_force != 0, p.N, p.M, allow_spec);
+        const int grid = (p.E + 1) / 2;
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(kRolesBlock), env->lds_bytes_roles, s, p);
+        HIP_TRY(hipGetLastError());
+        return DCC_OK;
+    }
     kernel_fn fn = pick_kernel(env->PPL, act, p.use_force != 0, p.N, p.M, allow_spec);
     const int grid = (p.E + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (env->lds_bytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)env->lds_bytes));
@@ -783,6 +983,8 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     p.env0 = 0; p.env_total = E;
 
     { const char* ns = std::getenv("DCC_NO_SPEC"); e->no_spec = ns && ns[0] == '1'; }
+    { const char* nr = std::getenv("DCC_NO_ROLES"); e->no_roles = nr && nr[0] == '1'; }
+    e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16) + 16 + (size_t)kStageC * 4;
     e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);
 
     auto cleanup = [&](int code, const std::string& m) { dcc_env_destroy(e); return fail(code, m); };

@@ -27,15 +27,22 @@ def _mk(c, z, E=None):
                                   c["comm_force_scale"])
 
 
-@pytest.mark.parametrize("nospec", ["0", "1"], ids=["spec", "generic"])
+@pytest.mark.parametrize("variant", ["spec-roles", "spec-fused", "generic-roles", "generic-fused"])
 @pytest.mark.parametrize("path", golden_env_files(), ids=lambda p: os.path.basename(p)[4:-4])
-def test_hip_step_matches_reference_golden(path, nospec, monkeypatch):
-    """nospec=1 forces the generic runtime-size kernel where a compile-time (N, M) specialisation
-    exists (BASELINE configs); both must reproduce the reference."""
+def test_hip_step_matches_reference_golden(path, variant, monkeypatch):
+    """Every kernel family must reproduce the reference: compile-time (N, M) specialisations vs the generic
+    runtime-size code (DCC_NO_SPEC=1), and the role-specialised physics/observation-wave kernel vs the fused
+    one-wave-per-env kernel (DCC_NO_ROLES=1)."""
     z, c = load_case(path)
-    if nospec == "1" and (c["N"], c["M"]) not in ((8, 64), (4, 16), (4, 20), (16, 256)):
-        pytest.skip("no specialised kernel for this size: generic path already covered")
-    monkeypatch.setenv("DCC_NO_SPEC", nospec)
+    spec, roles = variant.split("-")
+    has_spec = (c["N"], c["M"]) in ((8, 64), (4, 16), (4, 20), (16, 256))
+    has_roles = c["M"] <= 64
+    if spec == "generic" and not has_spec:
+        pytest.skip("no specialised kernel for this size: the generic path is what 'spec' already ran")
+    if roles == "fused" and not has_roles:
+        pytest.skip("more than one PoI per lane: only the fused kernel exists, 'roles' already ran it")
+    monkeypatch.setenv("DCC_NO_SPEC", "1" if spec == "generic" else "0")
+    monkeypatch.setenv("DCC_NO_ROLES", "1" if roles == "fused" else "0")
     env = _mk(c, z)
     dev = env.device
     obs0 = env.reset()
