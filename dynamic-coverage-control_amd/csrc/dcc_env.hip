@@ -637,7 +637,11 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? 3 : 4))) void dcc_
 // energies, done mask: ~0.5 KB) to wave 1 through a double-buffered LDS slot; wave 1 expands it into the
 // observation rows and streams them to HBM.  ready/consumed counters in LDS (workgroup-scope release/acquire)
 // let the physics wave run up to two steps ahead, so the observation wave always has a backlog.
-constexpr int kRolesBlock = 128;
+#ifndef DCC_ROLES_OWAVES
+#define DCC_ROLES_OWAVES 1
+#endif
+constexpr int kObsWaves = DCC_ROLES_OWAVES;          // observation waves per workgroup (1: both envs, 2: one env each)
+constexpr int kRolesBlock = 64 * (1 + kObsWaves);
 struct Handoff {  // one env, one slot; laid out in LDS as: apos[N] | avel[N] | en[64] | dmask(u64) | pad
     double2* apos; double2* avel; float* en; unsigned long long* dmask;
 };
@@ -660,7 +664,7 @@ __device__ __forceinline__ void publish(unsigned* flag, unsigned v, int lane) {
 }
 
 template <int ACT, bool FORCE, int NC, int MC>
-__global__ __launch_bounds__(kRolesBlock, 2) void dcc_env_roles_kernel(const KParams p) {
+__global__ __launch_bounds__(kRolesBlock, (kObsWaves == 2 ? 6 : 4)) void dcc_env_roles_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PPL = 1;
     constexpr bool SPEC = NC > 0;
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(kRolesBlock, 2) void dcc_env_roles_kernel(const KPa
     const int hb = handoff_bytes(N);
     unsigned char* hbase = smem + ((M * 16 + 15) & ~15);
     unsigned* flags = reinterpret_cast<unsigned*>(hbase + 4 * hb);
-    float* stg = reinterpret_cast<float*>(hbase + 4 * hb + 16);
+    float* stg = reinterpret_cast<float*>(hbase + 4 * hb + 16) + (role > 1 ? kStageC : 0);
 
     for (int j = threadIdx.x; j < M; j += kRolesBlock) s_poi[j] = p.poi[j];
     if (threadIdx.x < 4) flags[threadIdx.x] = 0u;
@@ -733,6 +737,7 @@ __global__ __launch_bounds__(kRolesBlock, 2) void dcc_env_roles_kernel(const KPa
             for (int s = 0; s < 2; ++s) {
                 const int env = env_base + s;
                 if (env >= p.E) continue;
+                if (kObsWaves == 2 && s != role - 1) continue;   // one env per observation wave
                 spin_until_ge(&flags[s], (unsigned)(k + 1));
                 Handoff h = handoff_at(hbase + (2 * s + (k & 1)) * hb, N);
                 float en[1];
@@ -984,7 +989,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
 
     { const char* ns = std::getenv("DCC_NO_SPEC"); e->no_spec = ns && ns[0] == '1'; }
     { const char* nr = std::getenv("DCC_NO_ROLES"); e->no_roles = nr && nr[0] == '1'; }
-    e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16) + 16 + (size_t)kStageC * 4;
+    e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16) + 16 + (size_t)kObsWaves * kStageC * 4;
     e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);
 
     auto cleanup = [&](int code, const std::string& m) { dcc_env_destroy(e); return fail(code, m); };
