@@ -291,7 +291,7 @@ def main():
             pass
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
-                           "kernel": "dcc_env_kernel<PPL,ACT,FORCE,NC,MC> (c2: <1,0,false,8,64>)", "bytes_per_env_step": bstep,
+                           "kernel": "dcc_env_roles_kernel<ACT,FORCE,NC,MC> (c2: <0,false,8,64>); DCC_NO_ROLES=1: dcc_env_kernel<1,0,false,8,64>", "bytes_per_env_step": bstep,
                            "launch_ms_avg": avg_ms, "launch_ms_min": min(ms), "launches_timed": len(ms),
                            "frac_of_achievable_6300": ach / 6300.0}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -4,7 +4,7 @@ d = sys.argv[1]; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 f = glob.glob(d + '/**/*_counter_collection.csv', recursive=True)[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if 'dcc_env_kernel' in r['Kernel_Name']:
+    if 'dcc_env' in r['Kernel_Name']:
         acc[(r['Kernel_Name'][-40:], r['Counter_Name'])].append((float(r['Counter_Value']), int(r['End_Timestamp']) - int(r['Start_Timestamp']), int(r['Grid_Size']), r['VGPR_Count'], r['SGPR_Count']))
 for (kn, k), v in sorted(acc.items()):
     big = [x for x in v if x[1] > 3e5]
