@@ -85,10 +85,11 @@ def test_hip_step_matches_reference_golden(path, variant, monkeypatch):
 
 
 @pytest.mark.parametrize("N,M,cfs,r_comm", [(8, 64, 0.0, 0.4), (8, 64, 0.5, 0.2), (5, 37, 0.5, 0.3), (16, 256, 0.5, 0.15),
-                                            (32, 1024, 0.5, 0.1), (3, 130, 1.0, 0.3), (64, 70, 0.5, 0.08)])
+                                            (32, 1024, 0.5, 0.1), (3, 130, 1.0, 0.3), (64, 70, 0.5, 0.08),
+                                            (64, 1024, 0.5, 0.05), (1, 1, 0.0, 0.4), (2, 64, 1.0, 0.3), (9, 500, 0.0, 0.2)])
 def test_hip_step_matches_oracle_random(N, M, cfs, r_comm, oracle_mod):
     """Seeded random actions, E=33 envs (not a multiple of the 4 envs per workgroup), 40 steps."""
-    E, T = 33, 40
+    E, T = (33, 40) if N * M < 20000 else (5, 12)
     rs = np.random.RandomState(N * 1000 + M)
     poi = rs.uniform(-1, 1, (M, 2))
     import dcc_hip
@@ -280,6 +281,10 @@ def test_argument_validation_raises():
         env.step(torch.zeros(2, 3, 2, device=dev), dict(reward=torch.zeros(3, device=dev)))
     with pytest.raises(dcc_hip.DccError):
         dcc_hip.HipCoverageEnv(2, 65, 4, np.zeros((4, 2)))
+    with pytest.raises(dcc_hip.DccError):
+        dcc_hip.HipCoverageEnv(0, 3, 4, poi)                                # empty batch
+    with pytest.raises(dcc_hip.DccError):
+        dcc_hip.HipCoverageEnv(2, 3, 1025, np.zeros((1025, 2)))            # above DCC_MAX_POIS
     with pytest.raises(dcc_hip.DccError):
         dcc_hip.HipCoverageEnv(2, 3, 4, poi, comm_r_scale=0.0, comm_force_scale=0.5)
     L = env.lib
