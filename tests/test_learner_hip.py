@@ -150,3 +150,14 @@ def test_headless_evaluation_dump(tmp_path):
     assert z["pos"].shape == (25, 8, 4, 2) and z["energy"].shape == (25, 8, 16) and z["poi"].shape == (16, 2)
     assert z["reward"].shape == (25, 8) and np.isfinite(z["reward"]).all()
     ptu.set_gpu_mode(False)
+
+
+def test_train_py_launcher_end_to_end(tmp_path):
+    """`cd dynamic-coverage-control_amd && python train.py 0 key=value...` (the reference's entry-point shape)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, "train.py", "0", "n_iters=2", "n_rollout_threads=32", "n_eval_rollout_threads=0",
+                        "max_ep_len=10", "ppo_epoch=2", "algo_hidden_size=32", "num_agents=4", "num_pois=16",
+                        "save_interval=2", "main_save_path=%s/" % tmp_path], cwd=PKG, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "iter: 2" in r.stdout and "value_loss" in r.stdout and "model saved" in r.stdout
