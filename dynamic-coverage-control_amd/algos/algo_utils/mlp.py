@@ -6,6 +6,7 @@ never-run `fc_h` template (mlp.py:21-23, 66,304 dead parameters per network, SUR
 created -- it would have `None` gradients and only complicate the gradient all-reduce.
 """
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .util import init
 
@@ -46,3 +47,31 @@ class MLPBase(nn.Module):
         if self._use_feature_normalization:
             x = self.feature_norm(x)
         return self.mlp(x)
+
+    # ---- input-normalisation cache for the PPO epochs ---------------------------------------------------
+    # LayerNorm(x) = xhat * gamma + beta with xhat = (x - mean) / sqrt(var + eps) independent of the
+    # parameters.  The observations of a rollout do not change over the ppo_epoch passes, so xhat is computed
+    # once per iteration and the affine part is folded into the first Linear:
+    #     W (xhat * gamma + beta) + b  =  (W * gamma) xhat + (W beta + b)
+    # which removes one LayerNorm forward + backward over the [B, obs_dim] input per epoch and network
+    # (the largest memory-bound kernels of the update).  Same function, gradients for gamma / beta flow
+    # through the folded weight and bias.
+    def normalize_input(self, x):
+        if not self._use_feature_normalization:
+            return x
+        ln = self.feature_norm
+        return F.layer_norm(x, ln.normalized_shape, None, None, ln.eps)
+
+    def forward_prenormalized(self, xhat):
+        lin = self.mlp.fc1[0]
+        if self._use_feature_normalization:
+            ln = self.feature_norm
+            w = lin.weight * ln.weight.unsqueeze(0)
+            b = lin.bias + lin.weight @ ln.bias
+            h = F.linear(xhat, w, b)
+        else:
+            h = lin(xhat)
+        h = self.mlp.fc1[2](self.mlp.fc1[1](h))
+        for blk in self.mlp.fc2:
+            h = blk(h)
+        return h

@@ -129,6 +129,8 @@ class MAPPOTrainer:
         # optional bf16 autocast of the update's GEMMs (MFMA bf16 = 16x the f32-MFMA rate); off by default
         # because the reference trains in fp32
         self.amp_bf16 = bool(getattr(cfg, "amp_bf16", False)) and ptu.device.type == "cuda"
+        # compute the parameter-free part of the input LayerNorm once per train() instead of once per epoch
+        self.cache_normalized_inputs = bool(getattr(cfg, "cache_normalized_inputs", True))
         self.value_normalizer = ValueNorm(1, device=ptu.device) if self._use_valuenorm else None
 
     # ---- losses ---------------------------------------------------------------------------------
@@ -152,7 +154,7 @@ class MAPPOTrainer:
             return (value_loss * active_masks_batch).sum() / active_masks_batch.sum()
         return value_loss.mean()
 
-    def ppo_update(self, sample, update_actor=True):
+    def ppo_update(self, sample, update_actor=True, prenormalized=False):
         """One full-batch PPO step (mappo.py:133-187).  `sample` is the 12-tuple of the reference's
         feed_forward_generator; tensors may be numpy (drop-in) or device tensors (native path).
         If `share_obs_batch` has fewer rows than `obs_batch` it holds ONE row per (step, env) and the
@@ -167,8 +169,9 @@ class MAPPOTrainer:
 
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp_bf16):
             action_log_probs, dist_entropy = self.policy.actor.evaluate_actions(
-                obs_batch, rnn_states_batch, actions_batch, masks_batch, available_actions_batch, active_masks_batch)
-            values = self.policy.critic(share_obs_batch)[0]
+                obs_batch, rnn_states_batch, actions_batch, masks_batch, available_actions_batch, active_masks_batch,
+                prenormalized=prenormalized)
+            values = self.policy.critic(share_obs_batch, prenormalized=prenormalized)[0]
         action_log_probs, dist_entropy, values = action_log_probs.float(), dist_entropy.float(), values.float()
         if values.shape[0] != obs_batch.shape[0]:
             n_rep = obs_batch.shape[0] // values.shape[0]
@@ -228,10 +231,18 @@ class MAPPOTrainer:
         info = {"value_loss": 0.0, "policy_loss": 0.0, "dist_entropy": 0.0, "actor_grad_norm": 0.0,
                 "critic_grad_norm": 0.0, "ratio": 0.0}
         acc = torch.zeros(6, dtype=torch.float64, device=ptu.device)
+        cached = None
+        if self.cache_normalized_inputs and self.num_mini_batch == 1:
+            with torch.no_grad():   # parameter-free: (x - mean) / sqrt(var + eps), once for all epochs
+                full = next(buffer.feed_forward_generator(advantages, 1, dedup_critic=self.dedup_critic))
+                cached = (self.policy.critic.base.normalize_input(ptu.to_tensor(full[0])),
+                          self.policy.actor.base.normalize_input(ptu.to_tensor(full[1])))
         for _ in range(self.ppo_epoch):
             for sample in buffer.feed_forward_generator(advantages, self.num_mini_batch,
                                                         dedup_critic=self.dedup_critic):
-                vl, cgn, pl, ent, agn, imp = self.ppo_update(sample, update_actor)
+                if cached is not None:
+                    sample = cached + tuple(sample[2:])
+                vl, cgn, pl, ent, agn, imp = self.ppo_update(sample, update_actor, prenormalized=cached is not None)
                 acc += torch.stack([vl.detach().double(), pl.detach().double(), ent.detach().double(),
                                     torch.as_tensor(agn, device=acc.device).double(),
                                     torch.as_tensor(cgn, device=acc.device).double(), imp.detach().mean().double()])

@@ -41,12 +41,14 @@ class R_Actor(nn.Module):
         actions, logp = self.act(feats, available_actions, deterministic)
         return actions, logp, rnn_states
 
-    def evaluate_actions(self, obs, rnn_states, action, masks, available_actions=None, active_masks=None):
+    def evaluate_actions(self, obs, rnn_states, action, masks, available_actions=None, active_masks=None,
+                         prenormalized=False):
+        """prenormalized: `obs` already went through MLPBase.normalize_input (see mlp.py)."""
         obs = check(obs).to(**self.tpdv)
         action = check(action).to(**self.tpdv)
         if active_masks is not None:
             active_masks = check(active_masks).to(**self.tpdv)
-        feats = self.base(obs)
+        feats = self.base.forward_prenormalized(obs) if prenormalized else self.base(obs)
         return self.act.evaluate_actions(feats, action, available_actions,
                                          active_masks=active_masks if self._use_policy_active_masks else None)
 
@@ -65,6 +67,7 @@ class R_Critic(nn.Module):
         self.v_out = init(nn.Linear(self.hidden_size, 1), init_method, lambda b: nn.init.constant_(b, 0))
         self.to(device)
 
-    def forward(self, cent_obs, rnn_states=None, masks=None):
+    def forward(self, cent_obs, rnn_states=None, masks=None, prenormalized=False):
         cent_obs = check(cent_obs).to(**self.tpdv)
-        return self.v_out(self.base(cent_obs)), rnn_states
+        feats = self.base.forward_prenormalized(cent_obs) if prenormalized else self.base(cent_obs)
+        return self.v_out(feats), rnn_states

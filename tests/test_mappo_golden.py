@@ -148,9 +148,10 @@ def test_share_obs_is_a_view_with_reference_shape():
     assert buf.share_obs_env.data_ptr() == buf.obs.data_ptr()      # no copy
 
 
+@pytest.mark.parametrize("cache", [False, True])
 @pytest.mark.parametrize("dedup", [False, True])
-def test_train_matches_reference(dedup):
-    cfg = make_cfg(dedup_critic=dedup)
+def test_train_matches_reference(dedup, cache):
+    cfg = make_cfg(dedup_critic=dedup, cache_normalized_inputs=cache)
     pol, tr = _policy(cfg)
     _set_vn(tr.value_normalizer, "vn0")
     buf = _filled_buffer(cfg)
