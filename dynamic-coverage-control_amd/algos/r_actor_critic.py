@@ -12,7 +12,8 @@ import torch.nn as nn
 
 from algos.algo_utils.act import ACTLayer
 from algos.algo_utils.mlp import MLPBase
-from algos.algo_utils.util import check, init
+from algos.algo_utils.util import init
+from utils.util import check
 from utils.util import get_shape_from_obs_space
 
 
