@@ -161,3 +161,21 @@ def test_train_py_launcher_end_to_end(tmp_path):
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "iter: 2" in r.stdout and "value_loss" in r.stdout and "model saved" in r.stdout
+
+
+@pytest.mark.parametrize("opt", ["use_hip_graph", "amp_bf16"])
+def test_optional_fast_paths_run(opt):
+    """The two optional switches (hipGraph-captured rollout, bf16 autocast of the policy GEMMs) stay healthy."""
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    lr = Learner(_cfg(n_rollout_threads=32, n_eval_rollout_threads=0, num_agents=4, num_pois=16, max_ep_len=12, n_iters=1,
+                      ppo_epoch=2, algo_hidden_size=32, save_model=False, **{opt: True}))
+    r_eager = lr.rollout(lr.rl_buffer, lr.train_envs)        # eager pass (+ capture when use_hip_graph)
+    r_again = lr.rollout(lr.rl_buffer, lr.train_envs)        # graph replay when use_hip_graph
+    info = lr.rl_update()
+    assert all(np.isfinite(v) for v in info.values()) and np.isfinite(r_again["reward"])
+    if opt == "use_hip_graph":
+        assert lr.use_hip_graph and len(lr._graphs) == 1, "capture must have succeeded on the GPU box"
+        assert torch.isfinite(lr.rl_buffer.returns).all()
+    ptu.set_gpu_mode(False)
