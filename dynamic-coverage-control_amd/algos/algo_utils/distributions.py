@@ -20,6 +20,14 @@ class AddBias(nn.Module):
 
 
 class FixedNormal(torch.distributions.Normal):
+    def sample(self, sample_shape=torch.Size()):
+        """mean + std * eps.  torch.normal(mean, std) -- what Normal.sample calls -- checks `std.min() >= 0` on the
+        host: a device synchronisation per rollout step and illegal inside a hipGraph capture."""
+        shape = self._extended_shape(sample_shape)
+        with torch.no_grad():
+            return self.loc.expand(shape) + self.scale.expand(shape) * torch.randn(shape, dtype=self.loc.dtype,
+                                                                                     device=self.loc.device)
+
     def log_probs(self, actions):
         return super().log_prob(actions).sum(-1, keepdim=True)
 
@@ -37,7 +45,9 @@ class DiagGaussian(nn.Module):
     def forward(self, x):
         mean = self.fc_mean(x)
         logstd = self.logstd(torch.zeros_like(mean))
-        return FixedNormal(mean, logstd.exp())
+        # validate_args=False: the default argument validation does `(scale > 0).all()` on the host -- a device
+        # synchronisation per call (and illegal inside a hipGraph capture); exp() is positive by construction
+        return FixedNormal(mean, logstd.exp(), validate_args=False)
 
 
 LOG_SQRT_2PI = 0.5 * math.log(2 * math.pi)
