@@ -195,3 +195,36 @@ def test_buffer_gae_has_no_cpu_path():
     from utils.valuenorm import ValueNorm
     with pytest.raises(dcc_hip.DccError):
         buf.compute_returns(torch.zeros(E, N, 1), ValueNorm(1))
+
+
+@pytest.mark.parametrize("dedup", [False, True])
+def test_mini_batch_generator_partitions_the_rollout(dedup):
+    """num_mini_batch > 1: mini-batches are drawn over (step, env) pairs, contain all N agents
+    of each pair, and together cover every row exactly once; the critic rows stay aligned with the agent rows."""
+    cfg = make_cfg(num_mini_batch=3, dedup_critic=dedup)
+    buf = _filled_buffer(cfg)
+    adv = torch.arange(T * E * N, dtype=torch.float32).view(T, E, N, 1)     # row id as the advantage
+    seen = []
+    torch.manual_seed(0)
+    for s in buf.feed_forward_generator(adv, 3, dedup_critic=dedup):
+        share, obs, acts, ids = s[0], s[1], s[4], s[10].view(-1).long()
+        assert obs.shape[0] == (T * E // 3) * N and ids.numel() == obs.shape[0]
+        assert share.shape[0] == (obs.shape[0] // N if dedup else obs.shape[0])
+        # rows really are the rows the ids name
+        np.testing.assert_array_equal(obs.numpy(), Z["buf_obs"][:-1].reshape(T * E * N, D)[ids.numpy()])
+        np.testing.assert_array_equal(acts.numpy(), Z["buf_actions"].reshape(T * E * N, A)[ids.numpy()])
+        pair = ids.view(-1, N)
+        assert bool((pair // N == pair[:, :1] // N).all())                  # all N agents of a (step, env) pair
+        so = Z["buf_obs"][:-1].reshape(T * E, S)[(pair[:, 0] // N).numpy()]
+        np.testing.assert_array_equal(share.numpy() if dedup else share.numpy()[::N], so)
+        seen.append(ids)
+    allids = torch.cat(seen)
+    assert allids.numel() == (T * E // 3) * 3 * N and allids.unique().numel() == allids.numel()
+
+
+def test_train_with_two_mini_batches_runs():
+    cfg = make_cfg(num_mini_batch=2)
+    pol, tr = _policy(cfg)
+    _set_vn(tr.value_normalizer, "vn0")
+    info = tr.train(_filled_buffer(cfg))
+    assert all(np.isfinite(v) for v in info.values())
