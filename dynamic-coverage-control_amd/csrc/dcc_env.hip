@@ -641,7 +641,11 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? 3 : 4))) void dcc_
 #define DCC_ROLES_OWAVES 1
 #endif
 constexpr int kObsWaves = DCC_ROLES_OWAVES;          // observation waves per workgroup (1: both envs, 2: one env each)
-constexpr int kRolesBlock = 64 * (1 + kObsWaves);
+#ifndef DCC_ROLES_PWAVES
+#define DCC_ROLES_PWAVES 1
+#endif
+constexpr int kPhysWaves = DCC_ROLES_PWAVES;        // physics waves per workgroup (1: both envs, 2: one env each)
+constexpr int kRolesBlock = 64 * (kPhysWaves + kObsWaves);
 struct Handoff {  // one env, one slot; laid out in LDS as: apos[N] | avel[N] | en[64] | dmask(u64) | pad
     double2* apos; double2* avel; float* en; unsigned long long* dmask;
 };
@@ -664,12 +668,13 @@ __device__ __forceinline__ void publish(unsigned* flag, unsigned v, int lane) {
 }
 
 template <int ACT, bool FORCE, int NC, int MC>
-__global__ __launch_bounds__(kRolesBlock, (kObsWaves == 2 ? 6 : 4)) void dcc_env_roles_kernel(const KParams p) {
+__global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : 4)) void dcc_env_roles_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PPL = 1;
     constexpr bool SPEC = NC > 0;
     const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 = physics, 1 = observation
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = wave < kPhysWaves ? 0 : 1 + (wave - kPhysWaves);   // 0 = physics, >= 1 = observation
     const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
     const int L = N * (4 + 2 * (N - 1) + 5 * M);
     const int env_base = blockIdx.x * 2;
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(kRolesBlock, (kObsWaves == 2 ? 6 : 4)) void dcc_env
         for (int s = 0; s < 2; ++s) {
             const int env = env_base + s;
             init_act(af[s]);
-            if (env < p.E) {
+            if (env < p.E && !(kPhysWaves == 2 && s != wave)) {
                 load_env_state<PPL>(p, env, lane, N, M, r[s]);
                 // the "previous" slot (1) holds the pre-move positions of step 0
                 Handoff h = handoff_at(hbase + (2 * s + 1) * hb, N);
@@ -709,6 +714,7 @@ __global__ __launch_bounds__(kRolesBlock, (kObsWaves == 2 ? 6 : 4)) void dcc_env
             for (int s = 0; s < 2; ++s) {
                 const int env = env_base + s;
                 if (env >= p.E) continue;
+                if (kPhysWaves == 2 && s != wave) continue;   // one env per physics wave
                 const int slot = k & 1;
                 Handoff out = handoff_at(hbase + (2 * s + slot) * hb, N);
                 Handoff in = handoff_at(hbase + (2 * s + (slot ^ 1)) * hb, N);
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(kRolesBlock, (kObsWaves == 2 ? 6 : 4)) void dcc_env
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-            if (env_base + s < p.E) store_env_state<PPL>(p, env_base + s, lane, N, M, r[s]);
+            if (env_base + s < p.E && !(kPhysWaves == 2 && s != wave)) store_env_state<PPL>(p, env_base + s, lane, N, M, r[s]);
     } else {
         // ---------------- observation wave: expand + stream, one env-step at a time ---------------------------
         // It is the wave that feeds HBM: it outranks the physics waves on its SIMD (they have slack).
