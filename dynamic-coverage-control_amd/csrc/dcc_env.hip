@@ -668,7 +668,7 @@ __device__ __forceinline__ void publish(unsigned* flag, unsigned v, int lane) {
 }
 
 template <int ACT, bool FORCE, int NC, int MC>
-__global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : 4)) void dcc_env_roles_kernel(const KParams p) {
+__global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (FORCE ? 3 : 4))) void dcc_env_roles_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PPL = 1;
     constexpr bool SPEC = NC > 0;
