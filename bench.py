@@ -156,8 +156,8 @@ def bench_mappo(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1500)
-    ap.add_argument("--warmup", type=int, default=150)
+    ap.add_argument("--steps", type=int, default=6000)
+    ap.add_argument("--warmup", type=int, default=600)
     ap.add_argument("--steps-per-launch", type=int, default=150)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=8)

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$R"
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
-BENCH="python bench.py --steps 1500 --warmup 150 --no-cpu-baseline"
+BENCH="python bench.py --no-cpu-baseline"
 # 1. un-profiled reference line
 $BENCH > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
 # 2. kernel trace + stats
