@@ -82,7 +82,8 @@ class HipCoverageVecEnv:
     def step_device(self, actions, obs_out=None, out=None):
         """actions: [E,N,2] float32/float64 tensor on the device.  Returns the dict of output tensors
         (obs, reward [E], done [E] u8, connect, connect_s, coverage [E], assign [E,M]).  `obs_out` lets
-        the caller name the destination of the observations (e.g. a rollout-buffer slot)."""
+        the caller name the destination of the observations (e.g. a rollout-buffer slot).  The small
+        per-step tensors are REUSED by the next call (no allocation per step): consume or copy them first."""
         if out is None:
             if self._out is None:
                 self._out = self.env.alloc_out(obs=False)
