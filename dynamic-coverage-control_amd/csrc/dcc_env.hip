@@ -173,6 +173,21 @@ struct Stager {
 // CU, shared by the resident waves) is relieved of loop control and index arithmetic.  NC = 0 is
 // the generic runtime-size code.
 
+// XCD-aware workgroup -> env-group mapping.  Workgroup b runs on XCD b % 8 (observed dispatch order; used for
+// speed only, never for correctness), and each XCD has its own L2.  The small per-step outputs ([K,E] arrays:
+// 1-4 bytes per env) of neighbouring envs share cache lines, so neighbouring envs should be written from the
+// SAME XCD, where the partial lines merge in one L2 before they reach HBM: workgroups b, b+8, b+16, ... (one
+// XCD) take consecutive env groups.
+__device__ __forceinline__ int xcd_swizzle(int b, int nblocks) {
+#ifdef DCC_NO_XCD_SWIZZLE
+    return b;
+#else
+    const int full = nblocks & ~7;          // blocks beyond the last multiple of 8 keep their index
+    if (b >= full) return b;
+    return (b & 7) * (full >> 3) + (b >> 3);
+#endif
+}
+
 constexpr int ACT_R = 2;  // action loads per lane and chunk
 
 // Per-lane registers of one env: lane i < N holds UAV i, lane l holds PoIs {l, l+64, ...}.
@@ -445,7 +460,17 @@ __device__ __forceinline__ void env_physics_step(const KParams& p, const int env
         n_done += __popcll(__ballot(valid && dn));
         n_just += __popcll(__ballot(just));
         if (valid && !dn) part -= __builtin_sqrt(smin);
-        if (valid && p.assign) p.assign[ko * M + j] = (uint8_t)amin;
+        if (p.assign) {
+            if ((M & 3) == 0) {
+                // four neighbouring lanes pack their index bytes into one dword (two quad-permute DPP moves):
+                // a 16-lane dword store instead of a 64-lane byte store
+                const int t1 = amin | (__builtin_amdgcn_update_dpp(0, amin, 0xF9, 0xF, 0xF, false) << 8);   // lane+1
+                const int t2 = t1 | (__builtin_amdgcn_update_dpp(0, t1, 0xEE, 0xF, 0xF, false) << 16);      // lane+2
+                if (valid && (lane & 3) == 0) *reinterpret_cast<unsigned*>(p.assign + ko * M + j) = (unsigned)t2;
+            } else if (valid) {
+                p.assign[ko * M + j] = (uint8_t)amin;
+            }
+        }
     }
     bool oob = false;
     if (lane < N) {
@@ -464,14 +489,19 @@ __device__ __forceinline__ void env_physics_step(const KParams& p, const int env
     // EN:106-108 sum over the N per-agent rewards; `just` bonus is paid once (SC:87-89)
     const double R = (double)N * base + p.rew_cover * (double)n_just;
     const bool env_done = all_done || any_oob;  // SC:112-117
-    if (lane == 0) {
-        if (p.reward) p.reward[ko] = (float)R;
-        if (p.reward64) p.reward64[ko] = R;
-        if (p.done) p.done[ko] = env_done ? 1 : 0;
-        if (p.connect) p.connect[ko] = connect ? 1 : 0;
-        if (p.connect_s) p.connect_s[ko] = connect_s ? 1 : 0;
-        if (p.coverage) p.coverage[ko] = (float)((double)n_done / (double)M);
+    // per-step scalars: one byte-store instruction for the three flags (lanes 0-2, one array each) and one
+    // dword-store instruction for reward and coverage (lanes 0-1) instead of five single-lane stores
+    if (lane < 3) {
+        uint8_t* dst = lane == 0 ? p.done : lane == 1 ? p.connect : p.connect_s;
+        const bool v = lane == 0 ? env_done : lane == 1 ? connect : connect_s;
+        if (dst) dst[ko] = v ? 1 : 0;
     }
+    if (lane < 2) {
+        float* dst = lane == 0 ? p.reward : p.coverage;
+        const float v = lane == 0 ? (float)R : (float)((double)n_done / (double)M);
+        if (dst) dst[ko] = v;
+    }
+    if (lane == 0 && p.reward64) p.reward64[ko] = R;
     // ---- (I) WR:104-109 auto-reset -> SC:64-78 ------------------------------------------------------
     if (env_done) {
         r.px = r.py = r.vx = r.vy = 0.0;
@@ -594,7 +624,7 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? 3 : 4))) void dcc_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int env = blockIdx.x * kWavesPerBlock + wid;
+    const int env = xcd_swizzle(blockIdx.x, gridDim.x) * kWavesPerBlock + wid;
     constexpr bool SPEC = NC > 0;
     const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
     const int L = N * (4 + 2 * (N - 1) + 5 * M);
@@ -677,7 +707,7 @@ __global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (
     const int role = wave < kPhysWaves ? 0 : 1 + (wave - kPhysWaves);   // 0 = physics, >= 1 = observation
     const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
     const int L = N * (4 + 2 * (N - 1) + 5 * M);
-    const int env_base = blockIdx.x * 2;
+    const int env_base = xcd_swizzle(blockIdx.x, gridDim.x) * 2;
 
     // LDS: PoI table | hand-off [env 0..1][slot 0..1] | flags ready[2], consumed[2] | staging window
     double2* s_poi = reinterpret_cast<double2*>(smem);
