@@ -201,10 +201,21 @@ struct EnvRegs {
 // Chunked action prefetch: lane (s*N + i) holds the action of agent i at step (chunk start + s);
 // ACT_R loads per lane -> ACT_R*(64/N) steps per chunk, so that the unavoidable vmcnt wait (which also
 // drains the wave's older stores) is paid once per chunk instead of once per step.
+// The chunk AFTER the current one is already in flight (fn / dn), so its HBM latency is hidden behind a
+// whole chunk of steps.
 struct ActFetch {
-    float2 f[ACT_R];
-    double2 d[ACT_R];
+    float2 f[ACT_R], fn[ACT_R];
+    double2 d[ACT_R], dn[ACT_R];
     int kc, r_sel, s_sel;
+};
+
+// Per-step outputs of one env, handed from the physics wave to the observation wave (role-specialised kernel):
+// the physics wave then issues no HBM store at all and never queues behind the observation stream.
+struct StepRec {
+    double R;
+    float cov;
+    unsigned flags;            // bit 0 done, bit 1 connect, bit 2 connect_s
+    unsigned char assign[64];  // PoI-assignment index of PoI `lane` (one PoI per lane)
 };
 
 // PoI coordinates of this lane: registers for <= 4 PoIs per lane, the LDS table otherwise.
@@ -231,13 +242,50 @@ struct PoiLane {
     }
 };
 
+// HBM stores of the per-step outputs of one env-step (ko = k*E + env).  amin: this lane's PoI-assignment
+// indices.  Flags: one byte-store instruction (lanes 0-2, one array each); reward / coverage: one dword-store
+// instruction (lanes 0-1); assignment: four neighbouring lanes pack their bytes into one dword (two
+// quad-permute DPP moves) -> a 16-lane dword store instead of a 64-lane byte store.
+template <int PPL>
+__device__ __forceinline__ void write_step_outputs(const KParams& p, const size_t ko, const int M, const int lane,
+                                                   const double R, const float cov, const bool env_done,
+                                                   const bool connect, const bool connect_s, const int (&amin)[PPL]) {
+    if (p.assign) {
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            const int j = q * 64 + lane;
+            const bool valid = j < M;
+            if ((M & 3) == 0) {
+                const int t1 = amin[q] | (__builtin_amdgcn_update_dpp(0, amin[q], 0xF9, 0xF, 0xF, false) << 8);   // lane+1
+                const int t2 = t1 | (__builtin_amdgcn_update_dpp(0, t1, 0xEE, 0xF, 0xF, false) << 16);            // lane+2
+                if (valid && (lane & 3) == 0) *reinterpret_cast<unsigned*>(p.assign + ko * M + j) = (unsigned)t2;
+            } else if (valid) {
+                p.assign[ko * M + j] = (uint8_t)amin[q];
+            }
+        }
+    }
+    if (lane < 3) {
+        uint8_t* dst = lane == 0 ? p.done : lane == 1 ? p.connect : p.connect_s;
+        const bool v = lane == 0 ? env_done : lane == 1 ? connect : connect_s;
+        if (dst) dst[ko] = v ? 1 : 0;
+    }
+    if (lane < 2) {
+        float* dst = lane == 0 ? p.reward : p.coverage;
+        const float v = lane == 0 ? (float)R : cov;
+        if (dst) dst[ko] = v;
+    }
+    if (lane == 0 && p.reward64) p.reward64[ko] = R;
+}
+
 // One reference env.step (phases A-F, H, I of SURVEY.md 3.3) of env `env` at fused step `k`.
 // apos_in: UAV positions BEFORE the move (LDS, [N]); apos_out / avel_out: where the post-step (and
-// post-auto-reset) positions / velocities go (may alias apos_in).  Per-step outputs go to HBM.
+// post-auto-reset) positions / velocities go (may alias apos_in).  Per-step outputs go to HBM, or into the LDS
+// record `rec` (one PoI per lane only) from which the observation wave stores them.
 template <int PPL, int ACT, bool FORCE, int NC, int MC>
 __device__ __forceinline__ void env_physics_step(const KParams& p, const int env, const int k, const int lane,
                                                  EnvRegs<PPL>& r, ActFetch& af, const PoiLane<PPL>& poi,
-                                                 const double2* apos_in, double2* apos_out, double2* avel_out) {
+                                                 const double2* apos_in, double2* apos_out, double2* avel_out,
+                                                 StepRec* rec = nullptr) {
     constexpr bool SPEC = NC > 0;
     const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
     constexpr int UNR_F = SPEC ? 4 : 2;  // unroll of the energy-pass loop over agents
@@ -247,7 +295,7 @@ __device__ __forceinline__ void env_physics_step(const KParams& p, const int env
     // ---- (A) EN:153-201 u = action; u *= 5.0 in the action's dtype ------------------------------
     float uxf = 0.f, uyf = 0.f;
     double uxd = 0, uyd = 0;
-    if (ACT == 2) {
+    if constexpr (ACT == 2) {
         if (lane < N) {
             const unsigned long long idx =
                 ((unsigned long long)(p.step0 + (unsigned)k) * (unsigned long long)p.env_total +
@@ -264,21 +312,29 @@ __device__ __forceinline__ void env_physics_step(const KParams& p, const int env
         if (af.kc == 0) {
             const int my_s = SPEC ? (lane / (SPEC ? NC : 1)) : (int)(((unsigned)lane * p.magicN) >> 20);  // lane / N
             const int my_i = lane - my_s * N;                                                              // lane % N
+            auto issue = [&](int k0) {   // loads of the chunk that starts at step k0 -> fn / dn
 #pragma unroll
-            for (int rr = 0; rr < ACT_R; ++rr) {
-                const int ks = k + rr * steps_per_load + my_s;
-                if (my_s < steps_per_load && ks < p.K) {
-                    const size_t ai = ((size_t)ks * p.E + env) * N + my_i;
-                    if (ACT == 1) af.d[rr] = reinterpret_cast<const double2*>(p.actions)[ai];
-                    else af.f[rr] = reinterpret_cast<const float2*>(p.actions)[ai];
+                for (int rr = 0; rr < ACT_R; ++rr) {
+                    const int ks = k0 + rr * steps_per_load + my_s;
+                    if (my_s < steps_per_load && ks < p.K) {
+                        const size_t ai = ((size_t)ks * p.E + env) * N + my_i;
+                        if (ACT == 1) af.dn[rr] = reinterpret_cast<const double2*>(p.actions)[ai];
+                        else af.fn[rr] = reinterpret_cast<const float2*>(p.actions)[ai];
+                    }
                 }
-            }
-            // consume the loads inside this branch: the wait is then paid only on chunk boundaries
+            };
+            // float32 actions (the production dtype): the chunk AFTER the current one is kept in flight, so the
+            // consume below finds loads that were issued a whole chunk of steps ago.  float64 actions (twice the
+            // registers) are loaded and consumed on the spot.
+            constexpr bool AHEAD = (ACT == 0);
+            if (!AHEAD || k == 0) issue(k);
+            // consume inside this branch: the vmcnt wait is paid only on chunk boundaries
 #pragma unroll
             for (int rr = 0; rr < ACT_R; ++rr) {
-                if (ACT == 1) asm volatile("" : "+v"(af.d[rr].x), "+v"(af.d[rr].y));
-                else asm volatile("" : "+v"(af.f[rr].x), "+v"(af.f[rr].y));
+                if (ACT == 1) { asm volatile("" : "+v"(af.dn[rr].x), "+v"(af.dn[rr].y)); af.d[rr] = af.dn[rr]; }
+                else { asm volatile("" : "+v"(af.fn[rr].x), "+v"(af.fn[rr].y)); af.f[rr] = af.fn[rr]; }
             }
+            if (AHEAD && k + chunk < p.K) issue(k + chunk);
         }
         if (af.s_sel == steps_per_load) { af.s_sel = 0; ++af.r_sel; }
         const int src = af.s_sel * N + lane;  // lane holding (step kc, agent = lane)
@@ -420,6 +476,7 @@ __device__ __forceinline__ void env_physics_step(const KParams& p, const int env
 
     // ---- (F) CW:157-174 update_energy + SC:80-97 reward terms on POST-move positions ---------------
     int n_done = 0, n_just = 0;
+    int amin_q[PPL];
     double part = 0.0;  // per-lane share of (OOB terms - sum of min distances)
 #pragma unroll
     for (int q = 0; q < PPL; ++q) {
@@ -460,17 +517,7 @@ __device__ __forceinline__ void env_physics_step(const KParams& p, const int env
         n_done += __popcll(__ballot(valid && dn));
         n_just += __popcll(__ballot(just));
         if (valid && !dn) part -= __builtin_sqrt(smin);
-        if (p.assign) {
-            if ((M & 3) == 0) {
-                // four neighbouring lanes pack their index bytes into one dword (two quad-permute DPP moves):
-                // a 16-lane dword store instead of a 64-lane byte store
-                const int t1 = amin | (__builtin_amdgcn_update_dpp(0, amin, 0xF9, 0xF, 0xF, false) << 8);   // lane+1
-                const int t2 = t1 | (__builtin_amdgcn_update_dpp(0, t1, 0xEE, 0xF, 0xF, false) << 16);      // lane+2
-                if (valid && (lane & 3) == 0) *reinterpret_cast<unsigned*>(p.assign + ko * M + j) = (unsigned)t2;
-            } else if (valid) {
-                p.assign[ko * M + j] = (uint8_t)amin;
-            }
-        }
+        amin_q[q] = amin;
     }
     bool oob = false;
     if (lane < N) {
@@ -489,19 +536,13 @@ __device__ __forceinline__ void env_physics_step(const KParams& p, const int env
     // EN:106-108 sum over the N per-agent rewards; `just` bonus is paid once (SC:87-89)
     const double R = (double)N * base + p.rew_cover * (double)n_just;
     const bool env_done = all_done || any_oob;  // SC:112-117
-    // per-step scalars: one byte-store instruction for the three flags (lanes 0-2, one array each) and one
-    // dword-store instruction for reward and coverage (lanes 0-1) instead of five single-lane stores
-    if (lane < 3) {
-        uint8_t* dst = lane == 0 ? p.done : lane == 1 ? p.connect : p.connect_s;
-        const bool v = lane == 0 ? env_done : lane == 1 ? connect : connect_s;
-        if (dst) dst[ko] = v ? 1 : 0;
+    const float cov = (float)((double)n_done / (double)M);
+    if (rec != nullptr) {
+        if (lane == 0) { rec->R = R; rec->cov = cov; rec->flags = (env_done ? 1u : 0u) | (connect ? 2u : 0u) | (connect_s ? 4u : 0u); }
+        rec->assign[lane] = (unsigned char)amin_q[0];
+    } else {
+        write_step_outputs<PPL>(p, ko, M, lane, R, cov, env_done, connect, connect_s, amin_q);
     }
-    if (lane < 2) {
-        float* dst = lane == 0 ? p.reward : p.coverage;
-        const float v = lane == 0 ? (float)R : (float)((double)n_done / (double)M);
-        if (dst) dst[ko] = v;
-    }
-    if (lane == 0 && p.reward64) p.reward64[ko] = R;
     // ---- (I) WR:104-109 auto-reset -> SC:64-78 ------------------------------------------------------
     if (env_done) {
         r.px = r.py = r.vx = r.vy = 0.0;
@@ -612,7 +653,9 @@ __device__ __forceinline__ void store_env_state(const KParams& p, int env, int l
 
 __device__ __forceinline__ void init_act(ActFetch& af) {
 #pragma unroll
-    for (int rr = 0; rr < ACT_R; ++rr) { af.f[rr] = make_float2(0.f, 0.f); af.d[rr] = make_double2(0.0, 0.0); }
+    for (int rr = 0; rr < ACT_R; ++rr) {
+        af.f[rr] = af.fn[rr] = make_float2(0.f, 0.f); af.d[rr] = af.dn[rr] = make_double2(0.0, 0.0);
+    }
     af.kc = 0; af.r_sel = 0; af.s_sel = 0;
 }
 
@@ -676,8 +719,8 @@ constexpr int kObsWaves = DCC_ROLES_OWAVES;          // observation waves per wo
 #endif
 constexpr int kPhysWaves = DCC_ROLES_PWAVES;        // physics waves per workgroup (1: both envs, 2: one env each)
 constexpr int kRolesBlock = 64 * (kPhysWaves + kObsWaves);
-struct Handoff {  // one env, one slot; laid out in LDS as: apos[N] | avel[N] | en[64] | dmask(u64) | pad
-    double2* apos; double2* avel; float* en; unsigned long long* dmask;
+struct Handoff {  // one env, one slot; laid out in LDS as: apos[N] | avel[N] | en[64] | dmask(u64) | pad | StepRec
+    double2* apos; double2* avel; float* en; unsigned long long* dmask; StepRec* rec;
 };
 __device__ __forceinline__ Handoff handoff_at(unsigned char* base, int N) {
     Handoff h;
@@ -685,9 +728,10 @@ __device__ __forceinline__ Handoff handoff_at(unsigned char* base, int N) {
     h.avel = h.apos + N;
     h.en = reinterpret_cast<float*>(h.avel + N);
     h.dmask = reinterpret_cast<unsigned long long*>(h.en + 64);
+    h.rec = reinterpret_cast<StepRec*>(h.en + 64 + 4);
     return h;
 }
-__device__ __forceinline__ int handoff_bytes(int N) { return N * 32 + 64 * 4 + 16; }
+__device__ __forceinline__ int handoff_bytes(int N) { return N * 32 + 64 * 4 + 16 + (int)sizeof(StepRec); }
 
 __device__ __forceinline__ void spin_until_ge(unsigned* flag, unsigned v) {
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(2);
@@ -751,7 +795,7 @@ __global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (
                 // slot `slot` was published at step k-2: wait until the observation wave has read it
                 if (k >= 2) spin_until_ge(&flags[2 + s], (unsigned)(k - 1));
                 if (p.mode == 0) {
-                    env_physics_step<PPL, ACT, FORCE, NC, MC>(p, env, k, lane, r[s], af[s], poi, in.apos, out.apos, out.avel);
+                    env_physics_step<PPL, ACT, FORCE, NC, MC>(p, env, k, lane, r[s], af[s], poi, in.apos, out.apos, out.avel, out.rec);
                 } else if (lane < N) {
                     out.apos[lane] = make_double2(r[s].px, r[s].py); out.avel[lane] = make_double2(r[s].vx, r[s].vy);
                 }
@@ -779,6 +823,13 @@ __global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (
                 float en[1];
                 en[0] = h.en[lane];
                 const unsigned dmask = (unsigned)((*h.dmask >> lane) & 1ULL);
+                if (p.mode == 0) {   // the physics wave's per-step outputs leave through this wave's store stream
+                    const unsigned fl = h.rec->flags;
+                    int am[1];
+                    am[0] = (int)h.rec->assign[lane];
+                    write_step_outputs<1>(p, (size_t)k * p.E + env, M, lane, h.rec->R, h.rec->cov, (fl & 1u) != 0u,
+                                          (fl & 2u) != 0u, (fl & 4u) != 0u, am);
+                }
                 produce_obs<PPL, FORCE, NC, MC>(p, p.obs + ((size_t)k * p.E + env) * (size_t)L, stg,
                                                 reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane);
                 publish(&flags[2 + s], (unsigned)(k + 1), lane);
@@ -1025,7 +1076,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
 
     { const char* ns = std::getenv("DCC_NO_SPEC"); e->no_spec = ns && ns[0] == '1'; }
     { const char* nr = std::getenv("DCC_NO_ROLES"); e->no_roles = nr && nr[0] == '1'; }
-    e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16) + 16 + (size_t)kObsWaves * kStageC * 4;
+    e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kObsWaves * kStageC * 4;
     e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);
 
     auto cleanup = [&](int code, const std::string& m) { dcc_env_destroy(e); return fail(code, m); };
