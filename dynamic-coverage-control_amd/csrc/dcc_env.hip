@@ -188,7 +188,10 @@ __device__ __forceinline__ int xcd_swizzle(int b, int nblocks) {
 #endif
 }
 
-constexpr int ACT_R = 2;  // action loads per lane and chunk
+// action loads per lane and chunk: 4 (x 64/N steps) for float32 actions when there is one PoI per lane, no pull-force
+// path and hence registers to spare (8 spills), else 2; 2 for float64 actions (twice the registers)
+template <int PPL, bool FORCE> constexpr int act_rf() { return (PPL == 1 && !FORCE) ? 4 : 2; }
+constexpr int ACT_RD = 2;
 
 // Per-lane registers of one env: lane i < N holds UAV i, lane l holds PoIs {l, l+64, ...}.
 template <int PPL>
@@ -199,13 +202,14 @@ struct EnvRegs {
 };
 
 // Chunked action prefetch: lane (s*N + i) holds the action of agent i at step (chunk start + s);
-// ACT_R loads per lane -> ACT_R*(64/N) steps per chunk, so that the unavoidable vmcnt wait (which also
+// R loads per lane -> R*(64/N) steps per chunk, so that the unavoidable vmcnt wait (which also
 // drains the wave's older stores) is paid once per chunk instead of once per step.
 // The chunk AFTER the current one is already in flight (fn / dn), so its HBM latency is hidden behind a
 // whole chunk of steps.
+template <int RF>
 struct ActFetch {
-    float2 f[ACT_R], fn[ACT_R];
-    double2 d[ACT_R], dn[ACT_R];
+    float2 f[RF], fn[RF];
+    double2 d[ACT_RD], dn[ACT_RD];
     int kc, r_sel, s_sel;
 };
 
@@ -283,7 +287,7 @@ __device__ __forceinline__ void write_step_outputs(const KParams& p, const size_
 // record `rec` (one PoI per lane only) from which the observation wave stores them.
 template <int PPL, int ACT, bool FORCE, int NC, int MC>
 __device__ __forceinline__ void env_physics_step(const KParams& p, const int env, const int k, const int lane,
-                                                 EnvRegs<PPL>& r, ActFetch& af, const PoiLane<PPL>& poi,
+                                                 EnvRegs<PPL>& r, ActFetch<act_rf<PPL, FORCE>()>& af, const PoiLane<PPL>& poi,
                                                  const double2* apos_in, double2* apos_out, double2* avel_out,
                                                  StepRec* rec = nullptr) {
     constexpr bool SPEC = NC > 0;
@@ -306,6 +310,7 @@ __device__ __forceinline__ void env_physics_step(const KParams& p, const int env
             uyf = ((float)lo * (1.0f / 8388608.0f) - 1.0f) * p.sens_f;
         }
     } else {
+        constexpr int ACT_R = (ACT == 1) ? ACT_RD : act_rf<PPL, FORCE>();
         const int steps_per_load = 64 / N;  // >= 1 because N <= 64
         const int chunk = ACT_R * steps_per_load;
         if (af.kc == chunk) { af.kc = 0; af.r_sel = 0; af.s_sel = 0; }
@@ -651,11 +656,12 @@ __device__ __forceinline__ void store_env_state(const KParams& p, int env, int l
     }
 }
 
-__device__ __forceinline__ void init_act(ActFetch& af) {
+template <int RF>
+__device__ __forceinline__ void init_act(ActFetch<RF>& af) {
 #pragma unroll
-    for (int rr = 0; rr < ACT_R; ++rr) {
-        af.f[rr] = af.fn[rr] = make_float2(0.f, 0.f); af.d[rr] = af.dn[rr] = make_double2(0.0, 0.0);
-    }
+    for (int rr = 0; rr < RF; ++rr) af.f[rr] = af.fn[rr] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int rr = 0; rr < ACT_RD; ++rr) af.d[rr] = af.dn[rr] = make_double2(0.0, 0.0);
     af.kc = 0; af.r_sel = 0; af.s_sel = 0;
 }
 
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? 3 : 4))) void dcc_
     load_env_state<PPL>(p, env, lane, N, M, r);
     if (lane < N) { apos[lane] = make_double2(r.px, r.py); avel[lane] = make_double2(r.vx, r.vy); }
     wave_fence();
-    ActFetch af;
+    ActFetch<act_rf<PPL, FORCE>()> af;
     init_act(af);
 
     for (int k = 0; k < p.K; ++k) {
@@ -770,7 +776,7 @@ __global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (
     if (role == 0) {
         // ---------------- physics wave: both envs of the workgroup, up to two steps ahead -------------------
         EnvRegs<PPL> r[2];
-        ActFetch af[2];
+        ActFetch<act_rf<PPL, FORCE>()> af[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int env = env_base + s;
