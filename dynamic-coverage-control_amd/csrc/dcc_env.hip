@@ -190,7 +190,7 @@ __device__ __forceinline__ int xcd_swizzle(int b, int nblocks) {
 
 // action loads per lane and chunk: 4 (x 64/N steps) for float32 actions when there is one PoI per lane, no pull-force
 // path and hence registers to spare (8 spills), else 2; 2 for float64 actions (twice the registers)
-template <int PPL, bool FORCE> constexpr int act_rf() { return (PPL == 1 && !FORCE) ? 4 : 2; }
+template <int PPL, bool FORCE> constexpr int act_rf() { return (PPL == 1 && !FORCE) ? 3 : 2; }
 constexpr int ACT_RD = 2;
 
 // Per-lane registers of one env: lane i < N holds UAV i, lane l holds PoIs {l, l+64, ...}.
@@ -669,7 +669,7 @@ __device__ __forceinline__ void init_act(ActFetch<RF>& af) {
 // Register budget: 4 waves/SIMD (<=128 VGPRs) keeps all 1024 workgroups of a 4096-env batch co-resident;
 // kernels that hold >= 8 PoIs per lane or the pull-force path trade occupancy for registers instead of spilling.
 template <int PPL, int ACT, bool FORCE, int NC, int MC>
-__global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? 3 : 4))) void dcc_env_kernel(const KParams p) {
+__global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? (PPL >= 4 ? 2 : 3) : 4))) void dcc_env_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
