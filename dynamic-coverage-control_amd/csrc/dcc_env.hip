@@ -253,8 +253,9 @@ struct PoiLane {
 template <int PPL>
 __device__ __forceinline__ void write_step_outputs(const KParams& p, const size_t ko, const int M, const int lane,
                                                    const double R, const float cov, const bool env_done,
-                                                   const bool connect, const bool connect_s, const int (&amin)[PPL]) {
-    if (p.assign) {
+                                                   const bool connect, const bool connect_s, const int (&amin)[PPL],
+                                                   const bool skip_assign = false) {
+    if (p.assign && !skip_assign) {
 #pragma unroll
         for (int q = 0; q < PPL; ++q) {
             const int j = q * 64 + lane;
@@ -562,17 +563,18 @@ __device__ __forceinline__ void env_physics_step(const KParams& p, const int env
 // ---- (G) SC:99-110 observation rows of one env-step, streamed through the LDS staging window --------
 // apv: flat view [pos | vel][N][2] of the (post-reset) UAV state in LDS; en / dmask: this lane's PoIs.
 template <int PPL, bool FORCE, int NC, int MC>
-__device__ __forceinline__ void produce_obs(const KParams& p, float* gout, float* stg, const double* apv,
+__device__ __forceinline__ void produce_obs(const KParams& p, Stager& st, const double* apv,
                                             const float (&en)[PPL], const unsigned dmask, const PoiLane<PPL>& poi,
-                                            const int lane) {
+                                            const int lane, const int flat_base = 0, const bool finish = true) {
+    // st: the staging window over the output stream that starts at st.gout; this env-step's block occupies the
+    // flat range [flat_base, flat_base + L) of it.  finish = false leaves the tail of the block in the window:
+    // the role-specialised kernel streams the adjacent blocks of its two envs as ONE stream, so the cache line
+    // that straddles the two blocks is written by one store instead of two half-line stores.
     constexpr bool SPEC = NC > 0;
     const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
     const int H = 4 + 2 * (N - 1), D = H + 5 * M, L = N * D;
     constexpr int UNR_O = SPEC ? ((NC <= 8 && !FORCE) ? NC : 2) : 1;  // full unroll -> static flush points
     const double2* apos = reinterpret_cast<const double2*>(apv);
-    Stager st;
-    st.stg = stg; st.w0 = 0; st.vec = SPEC ? 1 : p.vec_ok;
-    st.gout = gout;
 #pragma unroll UNR_O
     for (int i = 0; i < N; ++i) {
         const double2 xi = apos[i];
@@ -580,7 +582,7 @@ __device__ __forceinline__ void produce_obs(const KParams& p, float* gout, float
         //   f<2 -> avel[i][f&1]; f<4 -> apos[i][f&1]; else apos[k'][f&1] - x_i[f&1], k' skips i
         for (int f0 = 0; f0 < H; f0 += 64) {
             const int len = (H - f0) < 64 ? (H - f0) : 64;
-            float* dst = st.reserve(i * D + f0, len, lane);
+            float* dst = st.reserve(flat_base + i * D + f0, len, lane);
             const int f = f0 + lane;
             if (f < H) {
                 const int c = f & 1;
@@ -596,7 +598,7 @@ __device__ __forceinline__ void produce_obs(const KParams& p, float* gout, float
         for (int q = 0; q < PPL; ++q) {
             if (q * 64 < M) {
                 const int cntj = (M - q * 64) < 64 ? (M - q * 64) : 64;
-                float* dst = st.reserve(i * D + H + q * kTileFloats, 5 * cntj, lane);
+                float* dst = st.reserve(flat_base + i * D + H + q * kTileFloats, 5 * cntj, lane);
                 if (lane < cntj) {
                     float* d5 = dst + 5 * lane;
                     const double2 pj = poi.get(q);
@@ -609,7 +611,7 @@ __device__ __forceinline__ void produce_obs(const KParams& p, float* gout, float
             }
         }
     }
-    st.flush(L, lane);
+    if (finish) st.flush(flat_base + L, lane);
 }
 
 template <int PPL>
@@ -701,9 +703,12 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? (PPL >= 4 ? 2 : 3)
 
     for (int k = 0; k < p.K; ++k) {
         if (p.mode == 0) env_physics_step<PPL, ACT, FORCE, NC, MC>(p, env, k, lane, r, af, poi, apos, apos, avel);
-        if (p.obs)
-            produce_obs<PPL, FORCE, NC, MC>(p, p.obs + ((size_t)k * p.E + env) * (size_t)L, stg,
-                                            reinterpret_cast<const double*>(apos), r.en, r.dmask, poi, lane);
+        if (p.obs) {
+            Stager st;
+            st.stg = stg; st.w0 = 0; st.vec = SPEC ? 1 : p.vec_ok;
+            st.gout = p.obs + ((size_t)k * p.E + env) * (size_t)L;
+            produce_obs<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(apos), r.en, r.dmask, poi, lane);
+        }
     }
     store_env_state<PPL>(p, env, lane, N, M, r);
 }
@@ -818,6 +823,9 @@ __global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (
         // ---------------- observation wave: expand + stream, one env-step at a time ---------------------------
         // It is the wave that feeds HBM: it outranks the physics waves on its SIMD (they have slack).
         __builtin_amdgcn_s_setprio(3);
+        unsigned assign_w0 = 0;   // env 0's packed assignment row, held until env 1's is ready
+        Stager st;
+        st.stg = stg; st.w0 = 0; st.vec = SPEC ? 1 : p.vec_ok; st.gout = p.obs;
         for (int k = 0; k < p.K; ++k) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -833,11 +841,35 @@ __global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (
                     const unsigned fl = h.rec->flags;
                     int am[1];
                     am[0] = (int)h.rec->assign[lane];
+                    // The assignment rows of the workgroup's two envs are adjacent in HBM (2 x M bytes): with one
+                    // observation wave they are written by ONE store (a full 128-byte line at M = 64) instead of
+                    // two half-line stores a microsecond apart.
+                    const bool pair = kObsWaves == 1 && (M & 3) == 0 && p.assign != nullptr;
+                    if (pair) {
+                        const int nd = M >> 2;   // dwords per row (<= 16)
+                        const int t1 = am[0] | (__builtin_amdgcn_update_dpp(0, am[0], 0xF9, 0xF, 0xF, false) << 8);
+                        const int t2 = t1 | (__builtin_amdgcn_update_dpp(0, t1, 0xEE, 0xF, 0xF, false) << 16);
+                        const int rel = lane < nd ? lane : lane - nd;
+                        const unsigned w = (unsigned)__shfl(t2, 4 * (rel < nd ? rel : nd - 1), 64);   // dword `rel` of this row
+                        unsigned* row0 = reinterpret_cast<unsigned*>(p.assign + ((size_t)k * p.E + env_base) * M);
+                        const bool last_of_pair = (s == 1) || (env_base + 1 >= p.E);
+                        if (s == 0) assign_w0 = w;
+                        if (last_of_pair) {
+                            const int n_rows = (s == 1) ? 2 : 1;
+                            if (lane < n_rows * nd) row0[lane] = (s == 1 && lane >= nd) ? w : assign_w0;
+                        }
+                    }
                     write_step_outputs<1>(p, (size_t)k * p.E + env, M, lane, h.rec->R, h.rec->cov, (fl & 1u) != 0u,
-                                          (fl & 2u) != 0u, (fl & 4u) != 0u, am);
+                                          (fl & 2u) != 0u, (fl & 4u) != 0u, am, pair);
                 }
-                produce_obs<PPL, FORCE, NC, MC>(p, p.obs + ((size_t)k * p.E + env) * (size_t)L, stg,
-                                                reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane);
+                if (kObsWaves == 1) {   // both envs of the workgroup: one output stream of 2 L floats
+                    if (s == 0) { st.w0 = 0; st.gout = p.obs + ((size_t)k * p.E + env_base) * (size_t)L; }
+                    produce_obs<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane,
+                                                    s * L, (s == 1) || (env_base + 1 >= p.E));
+                } else {
+                    st.w0 = 0; st.gout = p.obs + ((size_t)k * p.E + env) * (size_t)L;
+                    produce_obs<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane);
+                }
                 publish(&flags[2 + s], (unsigned)(k + 1), lane);
             }
         }
