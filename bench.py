@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm-r-scale", type=float, default=0.95, help="0 disables the connectivity flags (profiling aid)")
     ap.add_argument("--no-assign", action="store_true", help="skip the PoI-assignment output (profiling aid)")
+    ap.add_argument("--no-scalars", action="store_true", help="skip reward/done/connect/coverage outputs (profiling aid)")
     ap.add_argument("--mode", choices=["env", "mappo"], default="env",
                     help="env: BASELINE config 2 (headline); mappo: config 3, full rollout + GAE + PPO update")
     ap.add_argument("--iters", type=int, default=2, help="--mode mappo: timed training iterations")
@@ -216,6 +217,8 @@ def main():
     env = dcc_hip.HipCoverageEnv(E, N, M, poi, r_cover, r_comm, crs, cfs, device=local_dev)
     env.reset()
     out = env.alloc_out(T, obs=not args.no_obs, assign=not args.no_assign)
+    if args.no_scalars:
+        out = {k: v for k, v in out.items() if k in ("obs", "assign")}
     actions = None
     if args.actions == "hbm":
         acts = np.stack([oracle.rng_actions(0, k, E, N, rank * E, world * E) for k in range(T)])
