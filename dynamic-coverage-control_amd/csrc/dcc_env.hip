@@ -36,9 +36,10 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = 64 * kWavesPerBlock;
 constexpr int kTileFloats = 5 * 64;  // one PoI tile of one agent row: 64 PoIs x 5 features
 #ifndef DCC_STAGE_C
-#define DCC_STAGE_C 2048
+#define DCC_STAGE_C 1024
 #endif
-constexpr int kStageC = DCC_STAGE_C;  // floats in the per-wave LDS staging window (8 KB)
+constexpr int kStageC = DCC_STAGE_C;  // floats in the per-wave LDS staging window (4 KB; ~3 obs rows at c2:
+                                      // flushes are small and frequent, which keeps the store stream smooth)
 
 struct KParams {
     int E, N, M, D, L, H;       // L = N*D floats per env, H = 4 + 2(N-1) header floats per agent row
