@@ -906,7 +906,7 @@ struct dcc_env {
     float* d_energy = nullptr;
     uint8_t* d_done = nullptr;
     size_t lds_bytes = 0, lds_bytes_roles = 0;
-    bool no_spec = false, no_roles = false;
+    bool no_spec = false, no_roles = false, force_roles = false;
 };
 
 namespace {
@@ -972,7 +972,9 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // observation-producing launches with one PoI per lane use the role-specialised kernel
     // (DCC_NO_ROLES=1 forces the fused kernel: tests, A/B)
-    if (p.obs != nullptr && env->PPL == 1 && !env->no_roles) {
+    // and only for fused multi-step launches: with K = 1 there is nothing to pipeline and the hand-off only adds
+    // latency (13.4 vs 14.3 us per single-step launch); DCC_FORCE_ROLES=1 overrides (tests)
+    if (p.obs != nullptr && env->PPL == 1 && !env->no_roles && (p.K >= 2 || env->force_roles)) {
         kernel_fn fn = pick_roles_kernel(act, p.use_force != 0, p.N, p.M, allow_spec);
         const int grid = (p.E + 1) / 2;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kRolesBlock), env->lds_bytes_roles, s, p);
@@ -1115,6 +1117,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
 
     { const char* ns = std::getenv("DCC_NO_SPEC"); e->no_spec = ns && ns[0] == '1'; }
     { const char* nr = std::getenv("DCC_NO_ROLES"); e->no_roles = nr && nr[0] == '1'; }
+    { const char* fr = std::getenv("DCC_FORCE_ROLES"); e->force_roles = fr && fr[0] == '1'; }
     e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kObsWaves * kStageC * 4;
     e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);
 

@@ -43,6 +43,7 @@ def test_hip_step_matches_reference_golden(path, variant, monkeypatch):
         pytest.skip("more than one PoI per lane: only the fused kernel exists, 'roles' already ran it")
     monkeypatch.setenv("DCC_NO_SPEC", "1" if spec == "generic" else "0")
     monkeypatch.setenv("DCC_NO_ROLES", "1" if roles == "fused" else "0")
+    monkeypatch.setenv("DCC_FORCE_ROLES", "1" if roles == "roles" else "0")   # single-step launches default to fused
     env = _mk(c, z)
     dev = env.device
     obs0 = env.reset()
