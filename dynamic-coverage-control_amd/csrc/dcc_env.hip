@@ -722,15 +722,7 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? (PPL >= 4 ? 2 : 3)
 // energies, done mask: ~0.5 KB) to wave 1 through a double-buffered LDS slot; wave 1 expands it into the
 // observation rows and streams them to HBM.  ready/consumed counters in LDS (workgroup-scope release/acquire)
 // let the physics wave run up to two steps ahead, so the observation wave always has a backlog.
-#ifndef DCC_ROLES_OWAVES
-#define DCC_ROLES_OWAVES 1
-#endif
-constexpr int kObsWaves = DCC_ROLES_OWAVES;          // observation waves per workgroup (1: both envs, 2: one env each)
-#ifndef DCC_ROLES_PWAVES
-#define DCC_ROLES_PWAVES 1
-#endif
-constexpr int kPhysWaves = DCC_ROLES_PWAVES;        // physics waves per workgroup (1: both envs, 2: one env each)
-constexpr int kRolesBlock = 64 * (kPhysWaves + kObsWaves);
+constexpr int kRolesBlock = 128;   // wave 0 = physics, wave 1 = observation (a second wave of either kind did not help)
 struct Handoff {  // one env, one slot; laid out in LDS as: apos[N] | avel[N] | en[64] | dmask(u64) | pad | StepRec
     double2* apos; double2* avel; float* en; unsigned long long* dmask; StepRec* rec;
 };
@@ -754,13 +746,12 @@ __device__ __forceinline__ void publish(unsigned* flag, unsigned v, int lane) {
 }
 
 template <int ACT, bool FORCE, int NC, int MC>
-__global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (FORCE ? 3 : 4))) void dcc_env_roles_kernel(const KParams p) {
+__global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PPL = 1;
     constexpr bool SPEC = NC > 0;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int role = wave < kPhysWaves ? 0 : 1 + (wave - kPhysWaves);   // 0 = physics, >= 1 = observation
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 = physics, 1 = observation
     const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
     const int L = N * (4 + 2 * (N - 1) + 5 * M);
     const int env_base = xcd_swizzle(blockIdx.x, gridDim.x) * 2;
@@ -770,7 +761,7 @@ __global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (
     const int hb = handoff_bytes(N);
     unsigned char* hbase = smem + ((M * 16 + 15) & ~15);
     unsigned* flags = reinterpret_cast<unsigned*>(hbase + 4 * hb);
-    float* stg = reinterpret_cast<float*>(hbase + 4 * hb + 16) + (role > 1 ? kStageC : 0);
+    float* stg = reinterpret_cast<float*>(hbase + 4 * hb + 16);
 
     for (int j = threadIdx.x; j < M; j += kRolesBlock) s_poi[j] = p.poi[j];
     if (threadIdx.x < 4) flags[threadIdx.x] = 0u;
@@ -787,7 +778,7 @@ __global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (
         for (int s = 0; s < 2; ++s) {
             const int env = env_base + s;
             init_act(af[s]);
-            if (env < p.E && !(kPhysWaves == 2 && s != wave)) {
+            if (env < p.E) {
                 load_env_state<PPL>(p, env, lane, N, M, r[s]);
                 // the "previous" slot (1) holds the pre-move positions of step 0
                 Handoff h = handoff_at(hbase + (2 * s + 1) * hb, N);
@@ -800,7 +791,6 @@ __global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (
             for (int s = 0; s < 2; ++s) {
                 const int env = env_base + s;
                 if (env >= p.E) continue;
-                if (kPhysWaves == 2 && s != wave) continue;   // one env per physics wave
                 const int slot = k & 1;
                 Handoff out = handoff_at(hbase + (2 * s + slot) * hb, N);
                 Handoff in = handoff_at(hbase + (2 * s + (slot ^ 1)) * hb, N);
@@ -819,7 +809,7 @@ __global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-            if (env_base + s < p.E && !(kPhysWaves == 2 && s != wave)) store_env_state<PPL>(p, env_base + s, lane, N, M, r[s]);
+            if (env_base + s < p.E) store_env_state<PPL>(p, env_base + s, lane, N, M, r[s]);
     } else {
         // ---------------- observation wave: expand + stream, one env-step at a time ---------------------------
         // It is the wave that feeds HBM: it outranks the physics waves on its SIMD (they have slack).
@@ -832,7 +822,6 @@ __global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (
             for (int s = 0; s < 2; ++s) {
                 const int env = env_base + s;
                 if (env >= p.E) continue;
-                if (kObsWaves == 2 && s != role - 1) continue;   // one env per observation wave
                 spin_until_ge(&flags[s], (unsigned)(k + 1));
                 Handoff h = handoff_at(hbase + (2 * s + (k & 1)) * hb, N);
                 float en[1];
@@ -845,7 +834,7 @@ __global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (
                     // The assignment rows of the workgroup's two envs are adjacent in HBM (2 x M bytes): with one
                     // observation wave they are written by ONE store (a full 128-byte line at M = 64) instead of
                     // two half-line stores a microsecond apart.
-                    const bool pair = kObsWaves == 1 && (M & 3) == 0 && p.assign != nullptr;
+                    const bool pair = (M & 3) == 0 && p.assign != nullptr;
                     if (pair) {
                         const int nd = M >> 2;   // dwords per row (<= 16)
                         const int t1 = am[0] | (__builtin_amdgcn_update_dpp(0, am[0], 0xF9, 0xF, 0xF, false) << 8);
@@ -863,14 +852,10 @@ __global__ __launch_bounds__(kRolesBlock, ((kObsWaves + kPhysWaves) == 3 ? 6 : (
                     write_step_outputs<1>(p, (size_t)k * p.E + env, M, lane, h.rec->R, h.rec->cov, (fl & 1u) != 0u,
                                           (fl & 2u) != 0u, (fl & 4u) != 0u, am, pair);
                 }
-                if (kObsWaves == 1) {   // both envs of the workgroup: one output stream of 2 L floats
-                    if (s == 0) { st.w0 = 0; st.gout = p.obs + ((size_t)k * p.E + env_base) * (size_t)L; }
-                    produce_obs<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane,
-                                                    s * L, (s == 1) || (env_base + 1 >= p.E));
-                } else {
-                    st.w0 = 0; st.gout = p.obs + ((size_t)k * p.E + env) * (size_t)L;
-                    produce_obs<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane);
-                }
+                // both envs of the workgroup: one output stream of 2 L floats
+                if (s == 0) { st.w0 = 0; st.gout = p.obs + ((size_t)k * p.E + env_base) * (size_t)L; }
+                produce_obs<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane,
+                                                s * L, (s == 1) || (env_base + 1 >= p.E));
                 publish(&flags[2 + s], (unsigned)(k + 1), lane);
             }
         }
@@ -1118,7 +1103,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     { const char* ns = std::getenv("DCC_NO_SPEC"); e->no_spec = ns && ns[0] == '1'; }
     { const char* nr = std::getenv("DCC_NO_ROLES"); e->no_roles = nr && nr[0] == '1'; }
     { const char* fr = std::getenv("DCC_FORCE_ROLES"); e->force_roles = fr && fr[0] == '1'; }
-    e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kObsWaves * kStageC * 4;
+    e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kStageC * 4;
     e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);
 
     auto cleanup = [&](int code, const std::string& m) { dcc_env_destroy(e); return fail(code, m); };
