@@ -349,3 +349,23 @@ def test_assignment_index_tie_on_rounded_distance(oracle_mod):
     assert np.array_equal(got, ref["assign"])
     n_tie = int((ref["assign"][:, 0] == 0).sum())
     assert 0 < n_tie < E, "the construction must produce both ties (index 0 wins) and non-ties (index 1 wins)"
+
+
+def test_long_rollout_stays_in_lockstep_with_oracle(oracle_mod):
+    """2,000 fused steps (13 action chunks of 24 steps... and hundreds of hand-offs between the physics and the
+    observation wave): done flags, rewards and the last observations still equal the oracle's."""
+    import dcc_hip
+    E, N, M, K = 66, 8, 64, 2000
+    poi = np.load(os.path.join(os.path.dirname(__file__), "golden", "pos_pois.npy"))[:M]
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, 0.4, 0.95, 0.0)
+    orc = oracle_mod.OracleEnv(E, N, M, poi, 0.2, 0.4, 0.95, 0.0)
+    env.reset(); orc.reset()
+    acts = np.stack([oracle_mod.rng_actions(77, k, E, N, 0, E) for k in range(K)])
+    out = env.rollout(K, actions=torch.from_numpy(acts).to(env.device))
+    ref = orc.rollout_rng(K, 77, 0, 0, E, want_obs_last=True)
+    assert np.array_equal(out["done"].cpu().numpy(), ref["done"])
+    np.testing.assert_allclose(out["reward"].cpu().numpy(), ref["reward"], rtol=REW_RTOL, atol=1e-5)
+    np.testing.assert_allclose(out["obs"][-1].cpu().numpy(), ref["obs_last"].astype(np.float32), rtol=0, atol=OBS_TOL)
+    assert int(ref["done"].sum()) > 0          # auto-resets happened along the way
+    st, so = env.get_state(), orc.get_state()
+    assert np.array_equal(st["pos"].cpu().numpy(), so["pos"]) and np.array_equal(st["done"].cpu().numpy(), so["done"])
