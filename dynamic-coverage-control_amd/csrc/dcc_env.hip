@@ -73,6 +73,11 @@ struct KParams {
     float* coverage;
     uint8_t* assign;
     double* reward64;
+    // compact post-step state outputs (leading K) / inputs of the expansion kernel
+    double2* st_pos;
+    double2* st_vel;
+    float* st_energy;
+    uint8_t* st_done;
 };
 
 __device__ __forceinline__ void wave_fence() {
@@ -643,6 +648,22 @@ __device__ __forceinline__ void load_env_state(const KParams& p, int env, int la
     for (int q = 0; q < PPL; ++q) asm volatile("" : "+v"(r.en[q]));
 }
 
+// Per-step compact state output (post-reset): what the observations of this env-step are a function of.
+template <int PPL>
+__device__ __forceinline__ void write_step_state(const KParams& p, const size_t ko, int lane, int N, int M,
+                                                 const EnvRegs<PPL>& r) {
+    if (p.st_pos && lane < N) p.st_pos[ko * N + lane] = make_double2(r.px, r.py);
+    if (p.st_vel && lane < N) p.st_vel[ko * N + lane] = make_double2(r.vx, r.vy);
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const int j = q * 64 + lane;
+        if (j < M) {
+            if (p.st_energy) p.st_energy[ko * M + j] = r.en[q];
+            if (p.st_done) p.st_done[ko * M + j] = (r.dmask >> q) & 1u;
+        }
+    }
+}
+
 template <int PPL>
 __device__ __forceinline__ void store_env_state(const KParams& p, int env, int lane, int N, int M, const EnvRegs<PPL>& r) {
     if (lane < N) {
@@ -704,6 +725,7 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? (PPL >= 4 ? 2 : 3)
 
     for (int k = 0; k < p.K; ++k) {
         if (p.mode == 0) env_physics_step<PPL, ACT, FORCE, NC, MC>(p, env, k, lane, r, af, poi, apos, apos, avel);
+        if (p.st_pos || p.st_vel || p.st_energy || p.st_done) write_step_state<PPL>(p, (size_t)k * p.E + env, lane, N, M, r);
         if (p.obs) {
             Stager st;
             st.stg = stg; st.w0 = 0; st.vec = SPEC ? 1 : p.vec_ok;
@@ -712,6 +734,45 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? (PPL >= 4 ? 2 : 3)
         }
     }
     store_env_state<PPL>(p, env, lane, N, M, r);
+}
+
+// ---- kernel 3: observation rows from compact state (dcc_obs_expand) ------------------------------------------
+// One wavefront per state: the same produce_obs() as the env kernels, fed from state arrays instead of a step.
+template <int PPL>
+__global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : 4)) void dcc_obs_expand_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = xcd_swizzle(blockIdx.x, gridDim.x) * kWavesPerBlock + wid;   // p.E = number of states
+    const int N = p.N, M = p.M;
+    const int L = N * (4 + 2 * (N - 1) + 5 * M);
+    double2* s_poi = reinterpret_cast<double2*>(smem);
+    const int per_wave = N * 32 + kStageC * 4;
+    unsigned char* wbase = smem + ((M * 16 + 15) & ~15) + wid * per_wave;
+    double2* apos = reinterpret_cast<double2*>(wbase);
+    double2* avel = apos + N;
+    float* stg = reinterpret_cast<float*>(avel + N);
+    for (int j = threadIdx.x; j < M; j += kBlock) s_poi[j] = p.poi[j];
+    __syncthreads();
+    if (n >= p.E) return;
+    PoiLane<PPL> poi;
+    poi.init(s_poi, lane, M);
+    if (lane < N) { apos[lane] = p.st_pos[(size_t)n * N + lane]; avel[lane] = p.st_vel[(size_t)n * N + lane]; }
+    float en[PPL];
+    unsigned dmask = 0;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const int j = q * 64 + lane;
+        en[q] = 0.f;
+        if (j < M) {
+            en[q] = p.st_energy[(size_t)n * M + j];
+            if (p.st_done[(size_t)n * M + j]) dmask |= 1u << q;
+        }
+    }
+    wave_fence();
+    Stager st;
+    st.stg = stg; st.w0 = 0; st.vec = p.vec_ok; st.gout = p.obs + (size_t)n * (size_t)L;
+    produce_obs<PPL, false, 0, 0>(p, st, reinterpret_cast<const double*>(apos), en, dmask, poi, lane);
 }
 
 // ---- kernel 2: role-specialised -- a PHYSICS wave and an OBSERVATION wave per workgroup --------------------
@@ -959,7 +1020,8 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
     // (DCC_NO_ROLES=1 forces the fused kernel: tests, A/B)
     // and only for fused multi-step launches: with K = 1 there is nothing to pipeline and the hand-off only adds
     // latency (13.4 vs 14.3 us per single-step launch); DCC_FORCE_ROLES=1 overrides (tests)
-    if (p.obs != nullptr && env->PPL == 1 && !env->no_roles && (p.K >= 2 || env->force_roles)) {
+    const bool state_out = p.st_pos || p.st_vel || p.st_energy || p.st_done;
+    if (p.obs != nullptr && env->PPL == 1 && !env->no_roles && !state_out && (p.K >= 2 || env->force_roles)) {
         kernel_fn fn = pick_roles_kernel(act, p.use_force != 0, p.N, p.M, allow_spec);
         const int grid = (p.E + 1) / 2;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kRolesBlock), env->lds_bytes_roles, s, p);
@@ -1000,6 +1062,10 @@ int fill_out(KParams& p, const dcc_env_out* out) {
     p.coverage = out ? out->coverage : nullptr;
     p.assign = out ? out->assign : nullptr;
     p.reward64 = out ? out->reward64 : nullptr;
+    p.st_pos = out ? reinterpret_cast<double2*>(out->state_pos) : nullptr;
+    p.st_vel = out ? reinterpret_cast<double2*>(out->state_vel) : nullptr;
+    p.st_energy = out ? out->state_energy : nullptr;
+    p.st_done = out ? out->state_done : nullptr;
     p.vec_ok = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 15u) == 0);
     return DCC_OK;
 }
@@ -1190,6 +1256,38 @@ int dcc_env_rollout(dcc_env* e, int32_t K, const float* actions, uint64_t seed, 
     p.seed = seed; p.step0 = step0; p.env0 = env0; p.env_total = env_total;
     fill_out(p, out);
     return launch(e, p, actions ? 0 : 2, stream);
+}
+
+int dcc_obs_expand(dcc_env* e, int64_t n, const double* pos, const double* vel, const float* energy,
+                   const uint8_t* done, float* obs, void* stream) {
+    if (!e) return fail(DCC_EINVAL, "dcc_obs_expand: null env");
+    if (n < 1 || n > 0x7fffffffLL) return fail(DCC_EINVAL, "dcc_obs_expand: n out of range");
+    if (!pos || !vel || !energy || !done || !obs) return fail(DCC_EINVAL, "dcc_obs_expand: null pointer");
+    if ((reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(vel)) & 15u)
+        return fail(DCC_EINVAL, "dcc_obs_expand: pos / vel must be 16-byte aligned");
+    DeviceGuard guard(e->device);
+    KParams p = e->base;
+    p.E = (int)n; p.K = 1; p.mode = 1;
+    dcc_env_out o;
+    std::memset(&o, 0, sizeof(o));
+    o.obs = obs;
+    fill_out(p, &o);
+    p.st_pos = reinterpret_cast<double2*>(const_cast<double*>(pos));
+    p.st_vel = reinterpret_cast<double2*>(const_cast<double*>(vel));
+    p.st_energy = const_cast<float*>(energy);
+    p.st_done = const_cast<uint8_t*>(done);
+    kernel_fn fn;
+    switch (e->PPL) {
+        case 1: fn = dcc_obs_expand_kernel<1>; break;
+        case 2: fn = dcc_obs_expand_kernel<2>; break;
+        case 4: fn = dcc_obs_expand_kernel<4>; break;
+        case 8: fn = dcc_obs_expand_kernel<8>; break;
+        default: fn = dcc_obs_expand_kernel<16>; break;
+    }
+    const int grid = (int)((n + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), e->lds_bytes, reinterpret_cast<hipStream_t>(stream), p);
+    HIP_TRY(hipGetLastError());
+    return DCC_OK;
 }
 
 int dcc_env_get_state(dcc_env* e, double* pos, double* vel, float* energy, uint8_t* done, void* stream) {

@@ -36,10 +36,11 @@ class EnvCfg(ctypes.Structure):
 
 class EnvOut(ctypes.Structure):
     _fields_ = [("obs", _vp), ("reward", _vp), ("done", _vp), ("connect", _vp), ("connect_s", _vp),
-                ("coverage", _vp), ("assign", _vp), ("reward64", _vp)]
+                ("coverage", _vp), ("assign", _vp), ("reward64", _vp),
+                ("state_pos", _vp), ("state_vel", _vp), ("state_energy", _vp), ("state_done", _vp)]
 
 
-EXPORTS = ["dcc_gae_compute", "dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
+EXPORTS = ["dcc_obs_expand", "dcc_gae_compute", "dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
            "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout", "dcc_env_get_state",
            "dcc_env_set_state", "dcc_env_bytes_per_step"]
 
@@ -73,8 +74,9 @@ def load_library(path=None):
     L.dcc_env_bytes_per_step.restype = ctypes.c_int64
     L.dcc_gae_compute.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, ctypes.c_int32,
                                   ctypes.c_int64, _vp]
-    if L.dcc_abi_version() != 1:
-        raise DccError("libdcc_hip.so ABI version %d != 1" % L.dcc_abi_version())
+    L.dcc_obs_expand.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]
+    if L.dcc_abi_version() != 2:
+        raise DccError("libdcc_hip.so ABI version %d != 2" % L.dcc_abi_version())
     _lib = L
     return L
 
@@ -150,6 +152,30 @@ class HipCoverageEnv:
             out["reward64"] = mk((self.E,), torch.float64)
         return out
 
+    def alloc_state_out(self, K=None):
+        """Compact post-step state outputs (ABI v2): add these to the `out` dict of step() / rollout()."""
+        lead = () if K is None else (K,)
+        mk = lambda shape, dt: torch.empty(lead + shape, dtype=dt, device=self.device)
+        return dict(state_pos=mk((self.E, self.N, 2), torch.float64), state_vel=mk((self.E, self.N, 2), torch.float64),
+                    state_energy=mk((self.E, self.M), torch.float32), state_done=mk((self.E, self.M), torch.uint8))
+
+    def expand_obs(self, pos, vel, energy, done, obs=None):
+        """obs [n,N,D] float32 from compact state (pos/vel [n,N,2] f64, energy [n,M] f32, done [n,M] u8)."""
+        n = pos.shape[0]
+        want = ((pos, (n, self.N, 2), torch.float64), (vel, (n, self.N, 2), torch.float64),
+                (energy, (n, self.M), torch.float32), (done, (n, self.M), torch.uint8))
+        for t, shape, dt in want:
+            if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("expand_obs: need contiguous %s %s on %s" % (shape, dt, self.device))
+        if obs is None:
+            obs = torch.empty((n, self.N, self.D), dtype=torch.float32, device=self.device)
+        elif tuple(obs.shape) != (n, self.N, self.D) or obs.dtype != torch.float32 or not obs.is_contiguous():
+            raise ValueError("expand_obs: obs must be contiguous float32 [n,N,D]")
+        with torch.cuda.device(self.device):
+            _check(self.lib.dcc_obs_expand(self._h, n, _ptr(pos), _ptr(vel), _ptr(energy), _ptr(done), _ptr(obs), _stream()),
+                   "dcc_obs_expand")
+        return obs
+
     def _out_struct(self, out, K=None):
         # the same output tensors are passed step after step: validate and build the C struct once
         key = (K,) + tuple((k, t.data_ptr()) for k, t in out.items() if t is not None)
@@ -163,9 +189,13 @@ class HipCoverageEnv:
         o = EnvOut()
         lead = () if K is None else (K,)
         shapes = dict(obs=(self.E, self.N, self.D), reward=(self.E,), done=(self.E,), connect=(self.E,),
-                      connect_s=(self.E,), coverage=(self.E,), assign=(self.E, self.M), reward64=(self.E,))
+                      connect_s=(self.E,), coverage=(self.E,), assign=(self.E, self.M), reward64=(self.E,),
+                      state_pos=(self.E, self.N, 2), state_vel=(self.E, self.N, 2), state_energy=(self.E, self.M),
+                      state_done=(self.E, self.M))
         dts = dict(obs=torch.float32, reward=torch.float32, done=torch.uint8, connect=torch.uint8,
-                   connect_s=torch.uint8, coverage=torch.float32, assign=torch.uint8, reward64=torch.float64)
+                   connect_s=torch.uint8, coverage=torch.float32, assign=torch.uint8, reward64=torch.float64,
+                   state_pos=torch.float64, state_vel=torch.float64, state_energy=torch.float32,
+                   state_done=torch.uint8)
         for k, t in out.items():
             if t is None:
                 continue

@@ -31,7 +31,7 @@ extern "C" {
 #define DCC_API
 #endif
 
-#define DCC_ABI_VERSION 1
+#define DCC_ABI_VERSION 2
 
 #define DCC_OK 0
 #define DCC_EINVAL (-1)   /* bad argument / shape */
@@ -82,6 +82,13 @@ typedef struct dcc_env_out {
     float*   coverage;   /* [E]  info["coverage_rate"] (mpe/uav_dcc.py:48) */
     uint8_t* assign;     /* [E,M] PoI-assignment index argmin_i ||x_i - p_j|| (first min), terminal positions */
     double*  reward64;   /* [E]  the same reward before the float32 cast (optional) */
+    /* ABI v2 -- compact state the observations are a function of (the state AFTER the step and after the
+     * auto-reset, i.e. exactly what `obs` was built from): 32N + 5M bytes per env-step instead of 4*N*D.
+     * A rollout buffer can store these and regenerate observations with dcc_obs_expand(). */
+    double*  state_pos;     /* [E,N,2] float64 */
+    double*  state_vel;     /* [E,N,2] float64 */
+    float*   state_energy;  /* [E,M]   float32 */
+    uint8_t* state_done;    /* [E,M]   uint8   */
 } dcc_env_out;
 
 DCC_API int         dcc_abi_version(void);
@@ -122,6 +129,13 @@ DCC_API int dcc_env_rollout(dcc_env* env, int32_t K, const float* actions, uint6
 DCC_API int dcc_env_get_state(dcc_env* env, double* pos, double* vel, float* energy, uint8_t* done, void* stream);
 DCC_API int dcc_env_set_state(dcc_env* env, const double* pos, const double* vel, const float* energy,
                       const uint8_t* done, void* stream);
+
+/* Observation rows from compact state: obs[n] = Scenario.observation of every agent (coverage.py:99-110) for n
+ * independent (env-)states laid out like the state_* outputs above (pos/vel [n,N,2] f64, energy [n,M] f32,
+ * done [n,M] u8) -> obs [n,N,D] float32.  Uses the PoI table and sizes of `env`; does not touch its state.
+ * Bit-identical to the obs the step that produced the state wrote. */
+DCC_API int dcc_obs_expand(dcc_env* env, int64_t n, const double* pos, const double* vel, const float* energy,
+                           const uint8_t* done, float* obs, void* stream);
 
 /* Algorithmic HBM bytes of one env-step (SURVEY.md section 8d, fp32 I/O contract):
  * 40N + 11M + 11 + 4*N*D; with_actions=0 drops 8N; with_obs=0 drops 4*N*D. */

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_libpath())
     for n in _declared():
         assert hasattr(lib, n), "missing export %s" % n
-    assert lib.dcc_abi_version() == 1
+    assert lib.dcc_abi_version() == 2
 
 
 def test_binding_lists_match_header():

@@ -369,3 +369,36 @@ def test_long_rollout_stays_in_lockstep_with_oracle(oracle_mod):
     assert int(ref["done"].sum()) > 0          # auto-resets happened along the way
     st, so = env.get_state(), orc.get_state()
     assert np.array_equal(st["pos"].cpu().numpy(), so["pos"]) and np.array_equal(st["done"].cpu().numpy(), so["done"])
+
+
+@pytest.mark.parametrize("N,M,cfs", [(8, 64, 0.0), (5, 37, 0.5), (16, 256, 0.5), (3, 7, 1.0)])
+def test_compact_state_outputs_and_obs_expansion(N, M, cfs, oracle_mod):
+    """ABI v2: the per-step compact state (post-reset pos / vel / energy / done) equals the oracle's state, and
+    dcc_obs_expand(state) reproduces -- bit for bit -- the observations the same steps wrote."""
+    import dcc_hip
+    E, K = 21, 30
+    rs = np.random.RandomState(N + M)
+    poi = rs.uniform(-1, 1, (M, 2))
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, 0.3, 0.95, cfs)
+    orc = oracle_mod.OracleEnv(E, N, M, poi, 0.2, 0.3, 0.95, cfs)
+    env.reset(); orc.reset()
+    acts = np.clip(rs.normal(0, 0.8, (K, E, N, 2)), -1, 1).astype(np.float32)
+    out = env.alloc_out(K)
+    out.update(env.alloc_state_out(K))
+    env.rollout(K, actions=torch.from_numpy(acts).to(env.device), out=out)
+    for k in range(K):
+        orc.step(acts[k], want_obs=False)
+        so = orc.get_state()                       # post-reset state, like the compact outputs
+        np.testing.assert_allclose(out["state_pos"][k].cpu().numpy(), so["pos"], rtol=0, atol=POS_TOL)
+        np.testing.assert_allclose(out["state_vel"][k].cpu().numpy(), so["vel"], rtol=0, atol=POS_TOL)
+        assert np.array_equal(out["state_energy"][k].cpu().numpy(), so["energy"].astype(np.float32))
+        assert np.array_equal(out["state_done"][k].cpu().numpy(), so["done"])
+    flat = lambda t: t.reshape((K * E,) + tuple(t.shape[2:]))
+    obs2 = env.expand_obs(flat(out["state_pos"]), flat(out["state_vel"]), flat(out["state_energy"]), flat(out["state_done"]))
+    assert torch.equal(obs2.view(K, E, N, env.D), out["obs"])
+    # single-step path too
+    o1 = env.alloc_out(); o1.update(env.alloc_state_out())
+    env.step(torch.from_numpy(acts[0]).to(env.device), o1)
+    assert torch.equal(env.expand_obs(o1["state_pos"], o1["state_vel"], o1["state_energy"], o1["state_done"]), o1["obs"])
+    with pytest.raises(ValueError):
+        env.expand_obs(o1["state_pos"].float(), o1["state_vel"], o1["state_energy"], o1["state_done"])
