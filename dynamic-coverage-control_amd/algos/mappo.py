@@ -131,14 +131,19 @@ class MAPPOTrainer:
         self.amp_bf16 = bool(getattr(cfg, "amp_bf16", False)) and ptu.device.type == "cuda"
         # compute the parameter-free part of the input LayerNorm once per train() instead of once per epoch
         self.cache_normalized_inputs = bool(getattr(cfg, "cache_normalized_inputs", True))
+        # > 0: visit the batch in chunks of this many rollout steps with gradient accumulation (exact);
+        # required by (and defaulted for) the compact-state rollout buffer
+        self.update_chunk_steps = int(getattr(cfg, "update_chunk_steps", 0))
         self.value_normalizer = ValueNorm(1, device=ptu.device) if self._use_valuenorm else None
 
     # ---- losses ---------------------------------------------------------------------------------
-    def cal_value_loss(self, values, value_preds_batch, return_batch, active_masks_batch):
-        """mappo.py:103-131 (ValueNorm.update happens here, once per ppo_update -- Q11)."""
+    def cal_value_loss(self, values, value_preds_batch, return_batch, active_masks_batch, update_norm=True):
+        """mappo.py:103-131 (ValueNorm.update happens here, once per ppo_update -- Q11; the chunked update calls
+        it once on the whole return batch and passes update_norm=False for its chunks)."""
         value_pred_clipped = value_preds_batch + (values - value_preds_batch).clamp(-self.clip_param, self.clip_param)
         if self._use_valuenorm:
-            self.value_normalizer.update(return_batch)
+            if update_norm:
+                self.value_normalizer.update(return_batch)
             target = self.value_normalizer.normalize(return_batch)
         else:
             target = return_batch
@@ -154,11 +159,8 @@ class MAPPOTrainer:
             return (value_loss * active_masks_batch).sum() / active_masks_batch.sum()
         return value_loss.mean()
 
-    def ppo_update(self, sample, update_actor=True, prenormalized=False):
-        """One full-batch PPO step (mappo.py:133-187).  `sample` is the 12-tuple of the reference's
-        feed_forward_generator; tensors may be numpy (drop-in) or device tensors (native path).
-        If `share_obs_batch` has fewer rows than `obs_batch` it holds ONE row per (step, env) and the
-        values are broadcast over the agents (dedup_critic)."""
+    def _forward_losses(self, sample, prenormalized=False, update_norm=True):
+        """Forward pass + the three loss terms of mappo.py:139-164 on one batch (or one chunk of it)."""
         (share_obs_batch, obs_batch, rnn_states_batch, rnn_states_critic_batch, actions_batch, value_preds_batch,
          return_batch, masks_batch, active_masks_batch, old_action_log_probs_batch, adv_targ,
          available_actions_batch) = sample
@@ -185,15 +187,11 @@ class MAPPOTrainer:
             policy_loss = (-surr * active_masks_batch).sum() / active_masks_batch.sum()
         else:
             policy_loss = -surr.mean()
-        value_loss = self.cal_value_loss(values, value_preds_batch, return_batch, active_masks_batch)
-        if update_actor:
-            total_loss = (policy_loss - dist_entropy * self.entropy_coef) + value_loss * self.value_loss_coef
-        else:
-            total_loss = value_loss * self.value_loss_coef
+        value_loss = self.cal_value_loss(values, value_preds_batch, return_batch, active_masks_batch, update_norm)
+        return policy_loss, dist_entropy, value_loss, imp_weights
 
-        self.policy.actor_optimizer.zero_grad(set_to_none=False)
-        self.policy.critic_optimizer.zero_grad(set_to_none=False)
-        total_loss.backward()
+    def _optimizer_step(self):
+        """all-reduce (multi-GPU) -> clip -> Adam, for both networks (mappo.py:176-185)."""
         actor_params = list(self.policy.actor.parameters())
         critic_params = list(self.policy.critic.parameters())
         _allreduce_grads(actor_params)
@@ -205,7 +203,54 @@ class MAPPOTrainer:
             actor_grad_norm, critic_grad_norm = get_gard_norm(actor_params), get_gard_norm(critic_params)
         self.policy.actor_optimizer.step()
         self.policy.critic_optimizer.step()
+        return actor_grad_norm, critic_grad_norm
+
+    def ppo_update(self, sample, update_actor=True, prenormalized=False):
+        """One full-batch PPO step (mappo.py:133-187).  `sample` is the 12-tuple of the reference's
+        feed_forward_generator; tensors may be numpy (drop-in) or device tensors (native path).
+        If `share_obs_batch` has fewer rows than `obs_batch` it holds ONE row per (step, env) and the
+        values are broadcast over the agents (dedup_critic)."""
+        policy_loss, dist_entropy, value_loss, imp_weights = self._forward_losses(sample, prenormalized)
+        if update_actor:
+            total_loss = (policy_loss - dist_entropy * self.entropy_coef) + value_loss * self.value_loss_coef
+        else:
+            total_loss = value_loss * self.value_loss_coef
+        self.policy.actor_optimizer.zero_grad(set_to_none=False)
+        self.policy.critic_optimizer.zero_grad(set_to_none=False)
+        total_loss.backward()
+        actor_grad_norm, critic_grad_norm = self._optimizer_step()
         return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights
+
+    def ppo_update_chunked(self, buffer, advantages, update_actor=True):
+        """The same full-batch PPO step with the batch visited in chunks of `update_chunk_steps` rollout steps
+        and the gradients accumulated: every loss term is a mean over the batch, so the chunk losses weighted by
+        their share of the rows add up to the full-batch loss (same gradient up to summation order).  Peak
+        activation memory is that of one chunk, and a compact-state buffer only ever materialises one chunk of
+        observations (dcc_obs_expand)."""
+        T = buffer.episode_length
+        step = max(1, int(self.update_chunk_steps))
+        if self._use_valuenorm:   # once per update on the whole return batch, like cal_value_loss does (Q11)
+            self.value_normalizer.update(buffer.returns[:-1].reshape(-1, 1))
+        # every row is active on this path (the env never deactivates an agent), so a chunk's weight is its row share
+        total_rows = float(T * buffer.n_rollout_threads * buffer.num_agents)
+        self.policy.actor_optimizer.zero_grad(set_to_none=False)
+        self.policy.critic_optimizer.zero_grad(set_to_none=False)
+        acc = None
+        for t0 in range(0, T, step):
+            t1 = min(T, t0 + step)
+            sample = buffer.chunk_sample(advantages, t0, t1, dedup_critic=self.dedup_critic)
+            w = sample[1].shape[0] / total_rows
+            policy_loss, dist_entropy, value_loss, imp_weights = self._forward_losses(sample, False, update_norm=False)
+            if update_actor:
+                loss = (policy_loss - dist_entropy * self.entropy_coef) + value_loss * self.value_loss_coef
+            else:
+                loss = value_loss * self.value_loss_coef
+            (loss * w).backward()
+            part = torch.stack([value_loss.detach(), policy_loss.detach(), dist_entropy.detach(),
+                                imp_weights.detach().mean()]).double() * w
+            acc = part if acc is None else acc + part
+        actor_grad_norm, critic_grad_norm = self._optimizer_step()
+        return acc[0], critic_grad_norm, acc[1], acc[2], actor_grad_norm, acc[3]
 
     # ---- one training phase -------------------------------------------------------------------------
     def normalized_advantages(self, buffer):
@@ -231,6 +276,22 @@ class MAPPOTrainer:
         info = {"value_loss": 0.0, "policy_loss": 0.0, "dist_entropy": 0.0, "actor_grad_norm": 0.0,
                 "critic_grad_norm": 0.0, "ratio": 0.0}
         acc = torch.zeros(6, dtype=torch.float64, device=ptu.device)
+        chunked = self.update_chunk_steps > 0 or getattr(buffer, "compact", False)
+        if chunked:
+            if self.num_mini_batch != 1:
+                raise NotImplementedError("chunked / compact-state updates are full-batch (num_mini_batch: 1)")
+            if self.update_chunk_steps <= 0:
+                self.update_chunk_steps = 10
+            for _ in range(self.ppo_epoch):
+                vl, cgn, pl, ent, agn, ratio = self.ppo_update_chunked(buffer, advantages, update_actor)
+                acc += torch.stack([vl.double(), pl.double(), ent.double(),
+                                    torch.as_tensor(agn, device=acc.device).double(),
+                                    torch.as_tensor(cgn, device=acc.device).double(), ratio.double()])
+            acc /= self.ppo_epoch
+            for k, v in zip(("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"),
+                            acc.tolist()):
+                info[k] = v
+            return info
         cached = None
         if self.cache_normalized_inputs and self.num_mini_batch == 1:
             with torch.no_grad():   # parameter-free: (x - mean) / sqrt(var + eps), once for all epochs

@@ -11,7 +11,12 @@ shapes, but:
     is an expanded view with the reference's [E, N, N*D] shape;
   * `compute_returns` is one launch of the HIP GAE scan (include/dcc_gae.h) -- there is no CPU path;
   * `feed_forward_generator` yields device tensors; with one mini-batch (the shipped setting) it
-    yields the whole batch without the randperm gather (the losses are means, order-free).
+    yields the whole batch without the randperm gather (the losses are means, order-free);
+  * compact mode (`compact=True`): the observations are a pure function of the env state
+    (pos, vel, PoI energy/done), which is 32N + 5M bytes per env-step instead of 4*N*D (576 B vs 10.8 KB at
+    8 UAV x 64 PoI).  The buffer then stores the state the env kernel emits (dcc_env_out.state_*), keeps only the
+    CURRENT step's observations for the policy forward, and `chunk_sample` regenerates the observations of a
+    range of steps with dcc_obs_expand (bit-identical) for the chunked PPO update.
 """
 import torch
 
@@ -20,7 +25,8 @@ from utils.util import get_shape_from_act_space, get_shape_from_obs_space
 
 
 class SharedReplayBuffer(object):
-    def __init__(self, cfg, obs_space, cent_obs_space, act_space, device=None):
+    def __init__(self, cfg, obs_space, cent_obs_space, act_space, device=None, compact=False, n_pois=None,
+                 expander=None):
         self.device = device if device is not None else ptu.device
         self.episode_length = cfg.max_ep_len
         self.n_rollout_threads = cfg.n_rollout_threads
@@ -36,8 +42,23 @@ class SharedReplayBuffer(object):
         self.obs_dim, self.share_obs_dim, self.act_dim = D, S, A
         self._shared_is_view = (S == N * D)
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
-        self.obs = z(T + 1, E, N, D)
-        self._share_obs = None if self._shared_is_view else z(T + 1, E, S)
+        self.compact = bool(compact)
+        if self.compact:
+            if not self._shared_is_view or n_pois is None or expander is None:
+                raise ValueError("compact buffer needs share_obs == concat(obs), n_pois and an expander "
+                                 "(HipCoverageEnv.expand_obs)")
+            self._expand = expander
+            self.obs = None
+            self.obs_cur = z(E, N, D)         # observations of the newest slot only
+            self._cur_slot = -1
+            self.state_pos = torch.zeros(T + 1, E, N, 2, dtype=torch.float64, device=self.device)
+            self.state_vel = torch.zeros(T + 1, E, N, 2, dtype=torch.float64, device=self.device)
+            self.state_energy = z(T + 1, E, n_pois)
+            self.state_done = torch.zeros(T + 1, E, n_pois, dtype=torch.uint8, device=self.device)
+            self._chunk_obs = None
+        else:
+            self.obs = z(T + 1, E, N, D)
+        self._share_obs = None if (self._shared_is_view or self.compact) else z(T + 1, E, S)
         self.value_preds = z(T + 1, E, N, 1)
         self.returns = z(T + 1, E, N, 1)
         self.advantages_raw = z(T, E, N, 1)
@@ -55,10 +76,74 @@ class SharedReplayBuffer(object):
         self.available_actions = None
         self.step = 0
 
+    # ---- slots the env kernel writes into / the policy reads from ----------------------------------------
+    def obs_slot(self, t):
+        """Destination of the observations of slot t ([E,N,D]).  Compact: the single current-step scratch."""
+        if self.compact:
+            self._cur_slot = t
+            return self.obs_cur
+        return self.obs[t]
+
+    def state_slot(self, t):
+        """dcc_env_out.state_* destinations of slot t (compact mode), else {}."""
+        if not self.compact:
+            return {}
+        return dict(state_pos=self.state_pos[t], state_vel=self.state_vel[t], state_energy=self.state_energy[t],
+                    state_done=self.state_done[t])
+
+    def set_state_slot(self, t, state):
+        """Copy an env state dict (HipCoverageEnv.get_state(): pos, vel, energy, done) into slot t."""
+        if self.compact:
+            self.state_pos[t].copy_(state["pos"]); self.state_vel[t].copy_(state["vel"])
+            self.state_energy[t].copy_(state["energy"]); self.state_done[t].copy_(state["done"])
+
+    def obs_at(self, t):
+        """[E,N,D] observations of slot t for the policy forward (compact: only the newest slot is resident)."""
+        if self.compact:
+            if t != self._cur_slot:
+                raise RuntimeError("compact buffer holds the observations of slot %d only, asked for %d"
+                                   % (self._cur_slot, t))
+            return self.obs_cur
+        return self.obs[t]
+
+    def share_obs_env_at(self, t):
+        """[E, S] centralised observation of slot t."""
+        if self.compact:
+            return self.obs_at(t).view(self.n_rollout_threads, -1)
+        return self.share_obs_env[t]
+
+    def obs_rows(self, t0, t1):
+        """[(t1-t0), E, N, D] observations of slots t0..t1-1; compact: regenerated from state into a reused chunk."""
+        if not self.compact:
+            return self.obs[t0:t1]
+        E, N, D = self.n_rollout_threads, self.num_agents, self.obs_dim
+        n = (t1 - t0) * E
+        if self._chunk_obs is None or self._chunk_obs.shape[0] < n:
+            self._chunk_obs = torch.empty(n, N, D, dtype=torch.float32, device=self.device)
+        out = self._chunk_obs[:n]
+        self._expand(self.state_pos[t0:t1].reshape(n, N, 2), self.state_vel[t0:t1].reshape(n, N, 2),
+                     self.state_energy[t0:t1].reshape(n, -1), self.state_done[t0:t1].reshape(n, -1), out)
+        return out.view(t1 - t0, E, N, D)
+
+    def chunk_sample(self, advantages, t0, t1, dedup_critic=False):
+        """The rows of steps t0..t1-1 as the reference's 12-tuple (shared_buffer.py:258-279), for the chunked
+        full-batch update (MAPPOTrainer.ppo_update_chunked)."""
+        E, N = self.n_rollout_threads, self.num_agents
+        n = (t1 - t0) * E
+        rows = lambda x: x[t0:t1].reshape(n * N, -1)
+        obs = self.obs_rows(t0, t1)
+        so_env = obs.reshape(n, N * self.obs_dim) if (self._shared_is_view or self.compact) else self._share_obs[t0:t1].reshape(n, -1)
+        so = so_env if dedup_critic else so_env.unsqueeze(1).expand(-1, N, -1).reshape(n * N, -1)
+        adv = torch.as_tensor(advantages).to(self.device, torch.float32)
+        return (so, obs.reshape(n * N, -1), None, None, rows(self.actions), rows(self.value_preds), rows(self.returns),
+                rows(self.masks), rows(self.active_masks), rows(self.action_log_probs), rows(adv), None)
+
     # ---- centralised observation -------------------------------------------------------------------
     @property
     def share_obs_env(self):
         """[T+1, E, S]: one centralised observation per env (what the critic is fed with dedup_critic)."""
+        if self.compact:
+            raise RuntimeError("compact buffer: use share_obs_env_at(t) / chunk_sample()")
         if self._shared_is_view:
             T1, E, N, D = self.obs.shape
             return self.obs.view(T1, E, N * D)
@@ -79,7 +164,8 @@ class SharedReplayBuffer(object):
         """shared_buffer.py:72-105.  `obs` may be None when the env kernel already wrote obs[step+1]."""
         s = self.step
         if obs is not None:
-            self.obs[s + 1].copy_(self._t(obs).view_as(self.obs[s + 1]))
+            dst = self.obs_slot(s + 1)
+            dst.copy_(self._t(obs).view_as(dst))
         if share_obs is not None and not self._shared_is_view:
             so = self._t(share_obs)
             self._share_obs[s + 1].copy_(so[:, 0] if so.dim() == 3 else so)
@@ -97,8 +183,13 @@ class SharedReplayBuffer(object):
 
     def after_update(self):
         """shared_buffer.py:142-152: the last slot becomes slot 0."""
-        self.obs[0].copy_(self.obs[-1])
-        if not self._shared_is_view:
+        if self.compact:
+            for a in (self.state_pos, self.state_vel, self.state_energy, self.state_done):
+                a[0].copy_(a[-1])
+            self._cur_slot = 0 if self._cur_slot == self.episode_length else self._cur_slot
+        else:
+            self.obs[0].copy_(self.obs[-1])
+        if self._share_obs is not None:
             self._share_obs[0].copy_(self._share_obs[-1])
         self.masks[0].copy_(self.masks[-1])
         self.bad_masks[0].copy_(self.bad_masks[-1])
@@ -125,6 +216,8 @@ class SharedReplayBuffer(object):
         over (step, env) pairs and contain all N agents of each pair."""
         T, E, N = self.episode_length, self.n_rollout_threads, self.num_agents
         num_mini_batch = num_mini_batch or 1
+        if self.compact:
+            raise RuntimeError("compact buffer: the batch is visited with chunk_sample() (ppo_update_chunked)")
         rows = lambda x: x.reshape(T * E * N, -1)
         adv = torch.as_tensor(advantages).to(self.device, torch.float32)
         if num_mini_batch == 1 and mini_batch_size is None:

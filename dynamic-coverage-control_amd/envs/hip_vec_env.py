@@ -79,17 +79,20 @@ class HipCoverageVecEnv:
     def reset_device(self, obs_out=None):
         return self.env.reset(obs_out)
 
-    def step_device(self, actions, obs_out=None, out=None):
+    def step_device(self, actions, obs_out=None, out=None, extra_out=None):
         """actions: [E,N,2] float32/float64 tensor on the device.  Returns the dict of output tensors
         (obs, reward [E], done [E] u8, connect, connect_s, coverage [E], assign [E,M]).  `obs_out` lets
         the caller name the destination of the observations (e.g. a rollout-buffer slot).  The small
-        per-step tensors are REUSED by the next call (no allocation per step): consume or copy them first."""
+        per-step tensors are REUSED by the next call (no allocation per step): consume or copy them first.
+        `extra_out` adds outputs to that dict (e.g. the compact state_* slots of a rollout buffer)."""
         if out is None:
             if self._out is None:
                 self._out = self.env.alloc_out(obs=False)
             out = dict(self._out)
             out["obs"] = obs_out if obs_out is not None else torch.empty(
                 (self.n_envs, self.n_agents, self.obs_dim), dtype=torch.float32, device=self.device)
+            if extra_out:
+                out.update(extra_out)
         return self.env.step(actions, out)
 
     # ---- numpy surface (reference contract) ----------------------------------------------------------

@@ -107,7 +107,9 @@ class Learner:
     def _make_buffer(self, envs):
         bcfg = copy.deepcopy(self.cfg)
         bcfg.n_rollout_threads = envs.n_envs
-        return SharedReplayBuffer(bcfg, envs.observation_space[0], envs.share_observation_space[0], envs.action_space[0])
+        compact = bool(getattr(self.cfg, "compact_obs", False))
+        return SharedReplayBuffer(bcfg, envs.observation_space[0], envs.share_observation_space[0], envs.action_space[0],
+                                  compact=compact, n_pois=envs.n_pois, expander=envs.env.expand_obs if compact else None)
 
     # ---- training loop (learner.py:132-175) ---------------------------------------------------------
     def train(self):
@@ -141,7 +143,8 @@ class Learner:
         cov_max = torch.zeros(r_envs.n_envs, dtype=torch.float32, device=ptu.device)
         for cur_step in range(self.max_ep_len):
             values, actions, action_log_probs = self.collect(cur_step, r_buffer)
-            out = r_envs.step_device(actions, obs_out=r_buffer.obs[cur_step + 1])
+            out = r_envs.step_device(actions, obs_out=r_buffer.obs_slot(cur_step + 1),
+                                     extra_out=r_buffer.state_slot(cur_step + 1))
             self.insert((out, values, actions, action_log_probs), r_buffer)
             rew_sum += out["reward"].double().mean()
             cov_max = torch.maximum(cov_max, out["coverage"])
@@ -181,7 +184,9 @@ class Learner:
 
     def warmup(self, r_buffer, r_envs):
         """reset every env; obs -> slot 0 (learner.py:216-225; share_obs is a view of obs here)."""
-        r_envs.reset_device(r_buffer.obs[0])
+        r_envs.reset_device(r_buffer.obs_slot(0))
+        if r_buffer.compact:
+            r_buffer.set_state_slot(0, r_envs.env.get_state())
         r_buffer.masks[0].fill_(1.0)
         r_buffer.step = 0
 
@@ -190,13 +195,14 @@ class Learner:
         """policy forward on the E*N agent rows, critic on the E env rows (learner.py:227-252)."""
         self.trainer.prep_rollout()
         E, N = r_buffer.n_rollout_threads, self.n_agents
-        obs = r_buffer.obs[cur_step].view(E * N, -1)
+        obs = r_buffer.obs_at(cur_step).view(E * N, -1)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.trainer.amp_bf16):
             actions, logp, _ = self.policy.actor(obs)
             if self.trainer.dedup_critic:
-                values = self.policy.critic(r_buffer.share_obs_env[cur_step])[0].view(E, 1, 1).expand(E, N, 1)
+                values = self.policy.critic(r_buffer.share_obs_env_at(cur_step))[0].view(E, 1, 1).expand(E, N, 1)
             else:
-                values = self.policy.critic(r_buffer.share_obs[cur_step].reshape(E * N, -1))[0].view(E, N, 1)
+                so = r_buffer.share_obs_env_at(cur_step).unsqueeze(1).expand(E, N, -1)
+                values = self.policy.critic(so.reshape(E * N, -1))[0].view(E, N, 1)
         return values.float(), actions.float().view(E, N, -1).contiguous(), logp.float().view(E, N, 1)
 
     def insert(self, data, r_buffer):
@@ -212,7 +218,7 @@ class Learner:
         """bootstrap value + GAE (learner.py:278-287 -> HIP scan)."""
         self.trainer.prep_rollout()
         E, N = r_buffer.n_rollout_threads, self.n_agents
-        next_values = self.policy.critic(r_buffer.share_obs_env[-1])[0].view(E, 1, 1).expand(E, N, 1)
+        next_values = self.policy.critic(r_buffer.share_obs_env_at(r_buffer.episode_length))[0].view(E, 1, 1).expand(E, N, 1)
         r_buffer.compute_returns(next_values, self.trainer.value_normalizer)
 
     # ---- update (learner.py:292-300) ---------------------------------------------------------------------

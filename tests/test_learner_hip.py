@@ -179,3 +179,37 @@ def test_optional_fast_paths_run(opt):
         assert lr.use_hip_graph and len(lr._graphs) == 1, "capture must have succeeded on the GPU box"
         assert torch.isfinite(lr.rl_buffer.returns).all()
     ptu.set_gpu_mode(False)
+
+
+def test_compact_state_buffer_trains_like_the_full_buffer():
+    """compact_obs: the rollout buffer keeps env state instead of observations and the update regenerates them
+    chunk by chunk with dcc_obs_expand.  Same seed -> the same rollout (bit-identical actions/rewards/returns),
+    regenerated observations bit-identical to the stored ones, and the same PPO step up to summation order."""
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    kw = dict(n_rollout_threads=48, n_eval_rollout_threads=0, num_agents=8, num_pois=64, max_ep_len=25, n_iters=1,
+              ppo_epoch=3, algo_hidden_size=64, save_model=False, seed=5, cache_normalized_inputs=False)
+    full = Learner(_cfg(**kw))
+    comp = Learner(_cfg(**dict(kw, compact_obs=True, update_chunk_steps=7)))
+    for (k, a), (_, b) in zip(full.policy.actor.state_dict().items(), comp.policy.actor.state_dict().items()):
+        assert torch.equal(a, b), k
+    torch.manual_seed(11); r_full = full.rollout(full.rl_buffer, full.train_envs)
+    torch.manual_seed(11); r_comp = comp.rollout(comp.rl_buffer, comp.train_envs)
+    fb, cb = full.rl_buffer, comp.rl_buffer
+    assert cb.compact and cb.obs is None
+    assert r_full == r_comp
+    for name in ("actions", "rewards", "masks", "value_preds", "returns", "action_log_probs"):
+        assert torch.equal(getattr(fb, name), getattr(cb, name)), name
+    T = fb.episode_length
+    for t0, t1 in ((0, 7), (7, 20), (20, T + 1)):
+        assert torch.equal(cb.obs_rows(t0, t1), fb.obs[t0:t1]), (t0, t1)
+    i_full, i_comp = full.rl_update(), comp.rl_update()
+    for k in i_full:
+        np.testing.assert_allclose(i_comp[k], i_full[k], rtol=2e-4, atol=1e-6, err_msg=k)
+    for (k, a), (_, b) in zip(full.policy.state_dict()["actor"].items(), comp.policy.state_dict()["actor"].items()):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-3, atol=2e-5, err_msg=k)
+    # a second iteration keeps working (after_update + warmup on the compact slots)
+    r2 = comp.rollout(comp.rl_buffer, comp.train_envs)
+    assert np.isfinite(r2["reward"]) and all(np.isfinite(v) for v in comp.rl_update().values())
+    ptu.set_gpu_mode(False)

@@ -228,3 +228,91 @@ def test_train_with_two_mini_batches_runs():
     _set_vn(tr.value_normalizer, "vn0")
     info = tr.train(_filled_buffer(cfg))
     assert all(np.isfinite(v) for v in info.values())
+
+
+# ---- chunked full-batch update / compact-state buffer ----------------------------------
+@pytest.mark.parametrize("chunk", [1, 3, 1000])
+@pytest.mark.parametrize("dedup", [False, True])
+def test_chunked_update_matches_reference(dedup, chunk):
+    """Gradient accumulation over chunks of rollout steps is the same full-batch PPO step: the reference's
+    post-update parameters, losses and ValueNorm state are reproduced to the same tolerances."""
+    cfg = make_cfg(dedup_critic=dedup, update_chunk_steps=chunk)
+    pol, tr = _policy(cfg)
+    _set_vn(tr.value_normalizer, "vn0")
+    buf = _filled_buffer(cfg)
+    tr.prep_training()
+    info = tr.train(buf, update_actor=True)
+    for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"):
+        np.testing.assert_allclose(info[k], float(Z["info_" + k]), rtol=2e-4, atol=1e-6, err_msg=k)
+    for pre, mod in (("actor2/", pol.actor), ("critic2/", pol.critic)):
+        for k, v in mod.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), Z[pre + k], rtol=1e-3, atol=2e-5, err_msg=pre + k)
+    np.testing.assert_allclose(tr.value_normalizer.running_mean.numpy(), Z["vn1_mean"], rtol=1e-5)
+    np.testing.assert_allclose(tr.value_normalizer.debiasing_term.numpy(), Z["vn1_debias"], rtol=1e-6)
+
+
+def _compact_buffer(cfg, n_pois=3):
+    """Compact buffer whose 'expander' is a table lookup keyed by state_energy[:, 0] (the real one is the HIP
+    kernel dcc_obs_expand, tested on the GPU): exercises the storage / chunking logic on the CPU."""
+    from buffer.shared_buffer import SharedReplayBuffer
+    table = torch.from_numpy(Z["buf_obs"]).reshape((T + 1) * E, N, D)
+    calls = []
+
+    def expander(pos, vel, energy, done, out):
+        assert pos.dtype == torch.float64 and done.dtype == torch.uint8 and pos.shape[0] == out.shape[0]
+        calls.append(out.shape[0])
+        out.copy_(table[energy[:, 0].long()])
+        return out
+
+    buf = SharedReplayBuffer(cfg, Box(D), Box(S), Box(A), compact=True, n_pois=n_pois, expander=expander)
+    buf.state_energy[:, :, 0] = torch.arange((T + 1) * E, dtype=torch.float32).view(T + 1, E)
+    for name, key in (("actions", "buf_actions"), ("action_log_probs", "buf_logp"), ("rewards", "buf_rewards"),
+                      ("value_preds", "buf_value_preds_after"), ("masks", "buf_masks"), ("returns", "returns")):
+        getattr(buf, name).copy_(torch.from_numpy(Z[key]))
+    return buf, calls
+
+
+def test_compact_buffer_update_matches_reference():
+    cfg = make_cfg(update_chunk_steps=4)
+    pol, tr = _policy(cfg)
+    _set_vn(tr.value_normalizer, "vn0")
+    buf, calls = _compact_buffer(cfg)
+    assert buf.obs is None and buf.obs_cur.shape == (E, N, D)
+    full = (T + 1) * E * N * D * 4
+    compact = sum(a.numel() * a.element_size() for a in (buf.state_pos, buf.state_vel, buf.state_energy, buf.state_done))
+    assert compact == (T + 1) * E * (32 * N + 5 * 3) and compact < full
+    tr.prep_training()
+    info = tr.train(buf, update_actor=True)
+    n_chunks = -(-T // 4)
+    assert len(calls) == n_chunks * cfg.ppo_epoch and max(calls) == 4 * E     # one chunk of observations at a time
+    for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"):
+        np.testing.assert_allclose(info[k], float(Z["info_" + k]), rtol=2e-4, atol=1e-6, err_msg=k)
+    for pre, mod in (("actor2/", pol.actor), ("critic2/", pol.critic)):
+        for k, v in mod.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), Z[pre + k], rtol=1e-3, atol=2e-5, err_msg=pre + k)
+
+
+def test_compact_buffer_slots_and_guards():
+    cfg = make_cfg()
+    buf, _ = _compact_buffer(cfg)
+    o1 = buf.obs_slot(1)
+    assert o1.data_ptr() == buf.obs_cur.data_ptr() and buf.obs_at(1) is buf.obs_cur
+    with pytest.raises(RuntimeError):
+        buf.obs_at(0)                       # only the newest slot's observations are resident
+    with pytest.raises(RuntimeError):
+        buf.share_obs_env
+    with pytest.raises(RuntimeError):
+        next(buf.feed_forward_generator(torch.zeros(T, E, N, 1)))
+    st = buf.state_slot(2)
+    assert st["state_pos"].data_ptr() == buf.state_pos[2].data_ptr() and st["state_done"].dtype == torch.uint8
+    buf.set_state_slot(0, dict(pos=torch.ones(E, N, 2, dtype=torch.float64), vel=torch.zeros(E, N, 2, dtype=torch.float64),
+                               energy=torch.full((E, 3), 7.0), done=torch.ones(E, 3, dtype=torch.uint8)))
+    assert float(buf.state_pos[0].sum()) == E * N * 2 and float(buf.state_energy[0, 0, 0]) == 7.0
+    buf.obs_slot(T)
+    buf.state_pos[-1].fill_(5.0)
+    buf.after_update()
+    assert float(buf.state_pos[0, 0, 0, 0]) == 5.0 and buf.obs_at(0) is buf.obs_cur
+    # the non-compact buffer answers the same slot API
+    plain = _filled_buffer(cfg)
+    assert plain.obs_slot(3).data_ptr() == plain.obs[3].data_ptr() and plain.state_slot(3) == {}
+    assert plain.share_obs_env_at(2).data_ptr() == plain.obs[2].data_ptr()
