@@ -8,6 +8,7 @@ created -- it would have `None` gradients and only complicate the gradient all-r
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused
 from .util import init
 
 
@@ -26,10 +27,17 @@ class MLPLayer(nn.Module):
         self.fc1 = _block(input_dim, hidden_size, use_orthogonal, use_ReLU)
         self.fc2 = nn.ModuleList([_block(hidden_size, hidden_size, use_orthogonal, use_ReLU) for _ in range(layer_N)])
 
+    @staticmethod
+    def run_block(blk, x):
+        """Linear -> act -> LayerNorm; the ReLU + LayerNorm tail is one fused HIP pass on the GPU (dcc_mlp.h)."""
+        if isinstance(blk[1], nn.ReLU):
+            return fused.relu_ln(blk[0](x), blk[2])
+        return blk(x)
+
     def forward(self, x):
-        x = self.fc1(x)
+        x = self.run_block(self.fc1, x)
         for blk in self.fc2:
-            x = blk(x)
+            x = self.run_block(blk, x)
         return x
 
 
@@ -71,7 +79,7 @@ class MLPBase(nn.Module):
             h = F.linear(xhat, w, b)
         else:
             h = lin(xhat)
-        h = self.mlp.fc1[2](self.mlp.fc1[1](h))
+        h = fused.relu_ln(h, self.mlp.fc1[2]) if isinstance(self.mlp.fc1[1], nn.ReLU) else self.mlp.fc1[2](self.mlp.fc1[1](h))
         for blk in self.mlp.fc2:
-            h = blk(h)
+            h = self.mlp.run_block(blk, h)
         return h

@@ -1,0 +1,137 @@
+"""First layer of actor and critic evaluated from compact features instead of observation rows.
+
+No counterpart in the reference: it builds every observation row (scenarios/coverage.py:99-110), stores it
+(buffer/shared_buffer.py:36-44) and feeds it to LayerNorm -> Linear (algos/algo_utils/mlp.py:45-58).  At
+8 UAV x 64 PoI a row has D = 1352 columns, and the centralised row N*D = 10816, of which only 4 + 2(N-1) = 18 per
+agent depend on the agent in a non-trivial way:
+
+    x_i = [ vel_i, pos_i, (pos_a - pos_i) for a != i  |  (poi_j - pos_i, energy_j, m_energy, done_j) for j ]
+
+With the LayerNorm affine folded into the Linear (W' = W * gamma, c = b + W beta) and (mu_i, rstd_i) the moments of
+row i,
+
+    Linear(LayerNorm(x_i)) = rstd_i * (x_i W'^T - mu_i * rowsum(W')) + c
+
+and x_i W'^T splits by linearity into
+
+    head_i W'_head^T  -  pos_i (sum_j W'_xy,j)^T                      per agent   (18 + 2 inputs)
+  + energy W'_e^T + done W'_d^T                                      per env     (2M inputs, shared by its agents)
+  + sum_j poi_j W'_xy,j^T + m_energy * sum_j W'_m,j                   constant    (once per parameter value)
+
+so the layer costs (2M/N + 2N + 2) multiply-adds per output and agent row instead of D (37x fewer at 8 x 64), reads
+~1/37 of the bytes, and the rows never exist.  The centralised critic is the same with per-agent weight blocks
+summed over the agents.  It is the same function of the parameters (a re-association of each dot product, 1e-6
+relative in fp32) and autograd differentiates it through the slicing/summing of the original parameters, so the
+parameters, their gradients and the optimizer state stay those of the reference's layer.  Inputs: the outputs of
+dcc_obs_features (include/dcc_env.h) or, for callers that hold rows, features_from_obs().
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import fused
+
+
+class ObsLayout(object):
+    """Column layout of an observation row (coverage.py:99-110) + the constants that appear in it."""
+
+    def __init__(self, n_agents, n_pois, poi_xy, m_energy):
+        self.N, self.M = int(n_agents), int(n_pois)
+        self.HD = 4 + 2 * (self.N - 1)
+        self.D = self.HD + 5 * self.M
+        self.poi_xy = torch.as_tensor(poi_xy, dtype=torch.float64).reshape(self.M, 2)
+        self.m_energy = float(m_energy)
+        self._poi32 = {}
+
+    def poi(self, like):
+        key = (like.device, like.dtype)
+        t = self._poi32.get(key)
+        if t is None:
+            t = self._poi32[key] = self.poi_xy.to(device=like.device, dtype=like.dtype)
+        return t
+
+
+def features_from_obs(obs, layout):
+    """The three feature tensors from materialised rows obs [n,N,D] (any device): what dcc_obs_features computes
+    from state.  Used where rows already exist (numpy drop-in callers, tests)."""
+    n, N, D = obs.shape
+    HD, M = layout.HD, layout.M
+    head = obs[..., :HD].contiguous()
+    blk = obs[:, 0, HD:].reshape(n, M, 5)
+    poi_feat = torch.cat([blk[..., 2], blk[..., 4]], dim=1).contiguous()
+    x = obs.double()
+    mean = x.mean(-1)
+    m2 = ((x - mean.unsqueeze(-1)) ** 2).sum(-1)
+    return dict(head=head, poi_feat=poi_feat, stats=torch.stack([mean, m2], dim=-1))
+
+
+def _folded(base):
+    lin = base.mlp.fc1[0]
+    if base._use_feature_normalization:
+        ln = base.feature_norm
+        return lin.weight * ln.weight.unsqueeze(0), lin.bias + lin.weight @ ln.bias, ln.eps
+    return lin.weight, lin.bias, None
+
+
+def _split(wf, layout):
+    """wf [..., D] -> head [..., HD], xy [..., M, 2], e/m/d [..., M]."""
+    HD, M = layout.HD, layout.M
+    poi = wf[..., HD:].reshape(wf.shape[:-1] + (M, 5))
+    return wf[..., :HD], poi[..., 0:2], poi[..., 2], poi[..., 3], poi[..., 4]
+
+
+def _tail(blk, z):
+    """activation + LayerNorm of a `Linear -> act -> LayerNorm` block on its pre-activation z (fused when ReLU)."""
+    if isinstance(blk[1], nn.ReLU):
+        return fused.relu_ln(z, blk[2])
+    return blk[2](blk[1](z))
+
+
+def _rest(base, h):
+    for blk in base.mlp.fc2:
+        h = _tail(blk, blk[0](h))
+    return h
+
+
+def actor_trunk(base, layout, feats):
+    """MLPBase(obs rows) for the n*N agent rows described by feats -> [n*N, H]."""
+    head, poi_feat, stats = feats["head"], feats["poi_feat"], feats["stats"]
+    n, N, HD = head.shape
+    wf, c, eps = _folded(base)                                   # [H, D], [H]
+    w_head, w_xy, w_e, w_m, w_d = _split(wf, layout)
+    w_h = torch.cat([w_head[:, :2], w_head[:, 2:4] - w_xy.sum(1), w_head[:, 4:]], dim=1)       # pos_i also shifts every PoI
+    const = (w_xy * layout.poi(wf)).sum((1, 2)) + layout.m_energy * w_m.sum(1)        # [H]
+    g = F.linear(poi_feat, torch.cat([w_e, w_d], dim=1), const).to(wf.dtype)                   # [n, H] shared by the agents
+    blk = base.mlp.fc1
+    if isinstance(blk[1], nn.ReLU):   # one fused pass: the pre-activation never reaches memory (include/dcc_mlp.h)
+        h = fused.actor_l1(head, g, stats if eps is not None else None, w_h, wf.sum(1), c, blk[2], eps, layout.D)
+        return _rest(base, h)
+    z = F.linear(head.reshape(n * N, HD), w_h).view(n, N, -1) + g.unsqueeze(1)
+    if eps is not None:
+        mean = stats[..., 0]
+        rstd = torch.rsqrt(stats[..., 1] / layout.D + eps)
+        z = rstd.to(wf.dtype).unsqueeze(-1) * (z - mean.to(wf.dtype).unsqueeze(-1) * wf.sum(1)) + c
+    else:
+        z = z + c
+    return _rest(base, _tail(blk, z.reshape(n * N, -1)))
+
+
+def critic_trunk(base, layout, feats):
+    """MLPBase(centralised rows = concat of the N agent rows of an env) -> [n, H]."""
+    head, poi_feat, stats = feats["head"], feats["poi_feat"], feats["stats"]
+    n, N, HD = head.shape
+    wf, c, eps = _folded(base)                                   # [H, N*D]
+    H = wf.shape[0]
+    w_head, w_xy, w_e, w_m, w_d = _split(wf.view(H, N, layout.D), layout)      # per-agent blocks
+    w_h = torch.cat([w_head[..., :2], w_head[..., 2:4] - w_xy.sum(2), w_head[..., 4:]], dim=-1).reshape(H, N * HD)
+    const = (w_xy * layout.poi(wf)).sum((1, 2, 3)) + layout.m_energy * w_m.sum((1, 2))
+    z = F.linear(head.reshape(n, N * HD), w_h) + F.linear(poi_feat, torch.cat([w_e.sum(1), w_d.sum(1)], dim=1), const).to(wf.dtype)
+    if eps is not None:
+        mean_i, m2_i = stats[..., 0], stats[..., 1]                            # [n, N] float64
+        mean = mean_i.mean(1, keepdim=True)
+        m2 = (m2_i + layout.D * (mean_i - mean) ** 2).sum(1, keepdim=True)     # pooled moments of the N*D-wide row
+        rstd = torch.rsqrt(m2 / (N * layout.D) + eps)
+        z = rstd.to(wf.dtype) * (z - mean.to(wf.dtype) * wf.sum(1)) + c
+    else:
+        z = z + c
+    return _rest(base, _tail(base.mlp.fc1, z))

@@ -45,6 +45,10 @@ class MAPPOPolicy:
         self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=self.critic_lr, eps=self.opti_eps,
                                                  weight_decay=self.weight_decay)
 
+    def enable_structured_input(self, layout):
+        """Let actor and critic accept compact features (algo_utils/structured.py) in place of observation rows."""
+        self.actor.obs_layout = self.critic.obs_layout = layout
+
     def broadcast_parameters(self, src=0):
         """Replicas start identical: rank `src`'s parameters are broadcast once (no-op single process)."""
         dist = _dist()
@@ -167,7 +171,11 @@ class MAPPOTrainer:
         t = lambda x: ptu.to_tensor(x) if x is not None else None
         old_logp, adv_targ = t(old_action_log_probs_batch), t(adv_targ)
         value_preds_batch, return_batch, active_masks_batch = t(value_preds_batch), t(return_batch), t(active_masks_batch)
-        obs_batch, share_obs_batch, actions_batch = t(obs_batch), t(share_obs_batch), t(actions_batch)
+        actions_batch = t(actions_batch)
+        structured_in = isinstance(obs_batch, dict)     # compact features of (step, env) states instead of rows
+        if not structured_in:
+            obs_batch, share_obs_batch = t(obs_batch), t(share_obs_batch)
+        n_rows = actions_batch.shape[0]
 
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp_bf16):
             action_log_probs, dist_entropy = self.policy.actor.evaluate_actions(
@@ -175,8 +183,8 @@ class MAPPOTrainer:
                 prenormalized=prenormalized)
             values = self.policy.critic(share_obs_batch, prenormalized=prenormalized)[0]
         action_log_probs, dist_entropy, values = action_log_probs.float(), dist_entropy.float(), values.float()
-        if values.shape[0] != obs_batch.shape[0]:
-            n_rep = obs_batch.shape[0] // values.shape[0]
+        if values.shape[0] != n_rows:
+            n_rep = n_rows // values.shape[0]
             values = values.unsqueeze(1).expand(-1, n_rep, -1).reshape(-1, 1)
 
         imp_weights = torch.exp(action_log_probs - old_logp)   # [B, A] when old_logp keeps the reference's [.,2] layout
@@ -239,7 +247,7 @@ class MAPPOTrainer:
         for t0 in range(0, T, step):
             t1 = min(T, t0 + step)
             sample = buffer.chunk_sample(advantages, t0, t1, dedup_critic=self.dedup_critic)
-            w = sample[1].shape[0] / total_rows
+            w = sample[4].shape[0] / total_rows
             policy_loss, dist_entropy, value_loss, imp_weights = self._forward_losses(sample, False, update_norm=False)
             if update_actor:
                 loss = (policy_loss - dist_entropy * self.entropy_coef) + value_loss * self.value_loss_coef
@@ -280,8 +288,8 @@ class MAPPOTrainer:
         if chunked:
             if self.num_mini_batch != 1:
                 raise NotImplementedError("chunked / compact-state updates are full-batch (num_mini_batch: 1)")
-            if self.update_chunk_steps <= 0:
-                self.update_chunk_steps = 10
+            if self.update_chunk_steps <= 0:   # rows are regenerated per chunk: keep them small; features are tiny
+                self.update_chunk_steps = buffer.episode_length if getattr(buffer, "structured", False) else 10
             for _ in range(self.ppo_epoch):
                 vl, cgn, pl, ent, agn, ratio = self.ppo_update_chunked(buffer, advantages, update_actor)
                 acc += torch.stack([vl.double(), pl.double(), ent.double(),

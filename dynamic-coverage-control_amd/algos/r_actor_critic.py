@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from algos.algo_utils.act import ACTLayer
 from algos.algo_utils.mlp import MLPBase
+from algos.algo_utils import structured
 from algos.algo_utils.util import init
 from utils.util import check
 from utils.util import get_shape_from_obs_space
@@ -34,22 +35,30 @@ class R_Actor(nn.Module):
         _require_mlp(cfg, obs_shape)
         self.base = MLPBase(cfg, obs_shape)
         self.act = ACTLayer(action_space, self.hidden_size, cfg.use_orthogonal, cfg.gain)
+        self.obs_layout = None    # set by MAPPOPolicy.enable_structured_input
         self.to(device)
 
-    def forward(self, obs, rnn_states=None, masks=None, available_actions=None, deterministic=False):
+    def _trunk(self, obs, prenormalized=False):
+        """obs: rows [B, D], or the dict of compact features of B/N env states (algo_utils/structured.py)."""
+        if isinstance(obs, dict):
+            if self.obs_layout is None:
+                raise RuntimeError("compact features passed to an actor without an observation layout")
+            return structured.actor_trunk(self.base, self.obs_layout, obs)
         obs = check(obs).to(**self.tpdv)
-        feats = self.base(obs)
+        return self.base.forward_prenormalized(obs) if prenormalized else self.base(obs)
+
+    def forward(self, obs, rnn_states=None, masks=None, available_actions=None, deterministic=False):
+        feats = self._trunk(obs)
         actions, logp = self.act(feats, available_actions, deterministic)
         return actions, logp, rnn_states
 
     def evaluate_actions(self, obs, rnn_states, action, masks, available_actions=None, active_masks=None,
                          prenormalized=False):
         """prenormalized: `obs` already went through MLPBase.normalize_input (see mlp.py)."""
-        obs = check(obs).to(**self.tpdv)
         action = check(action).to(**self.tpdv)
         if active_masks is not None:
             active_masks = check(active_masks).to(**self.tpdv)
-        feats = self.base.forward_prenormalized(obs) if prenormalized else self.base(obs)
+        feats = self._trunk(obs, prenormalized)
         return self.act.evaluate_actions(feats, action, available_actions,
                                          active_masks=active_masks if self._use_policy_active_masks else None)
 
@@ -66,9 +75,16 @@ class R_Critic(nn.Module):
         self.base = MLPBase(cfg, shape)
         init_method = nn.init.orthogonal_ if cfg.use_orthogonal else nn.init.xavier_uniform_
         self.v_out = init(nn.Linear(self.hidden_size, 1), init_method, lambda b: nn.init.constant_(b, 0))
+        self.obs_layout = None
         self.to(device)
 
     def forward(self, cent_obs, rnn_states=None, masks=None, prenormalized=False):
-        cent_obs = check(cent_obs).to(**self.tpdv)
-        feats = self.base.forward_prenormalized(cent_obs) if prenormalized else self.base(cent_obs)
+        """cent_obs: rows [B, N*D], or the dict of compact features of B env states (one value per env)."""
+        if isinstance(cent_obs, dict):
+            if self.obs_layout is None:
+                raise RuntimeError("compact features passed to a critic without an observation layout")
+            feats = structured.critic_trunk(self.base, self.obs_layout, cent_obs)
+        else:
+            cent_obs = check(cent_obs).to(**self.tpdv)
+            feats = self.base.forward_prenormalized(cent_obs) if prenormalized else self.base(cent_obs)
         return self.v_out(feats), rnn_states

@@ -26,7 +26,7 @@ from utils.util import get_shape_from_act_space, get_shape_from_obs_space
 
 class SharedReplayBuffer(object):
     def __init__(self, cfg, obs_space, cent_obs_space, act_space, device=None, compact=False, n_pois=None,
-                 expander=None):
+                 expander=None, featurizer=None):
         self.device = device if device is not None else ptu.device
         self.episode_length = cfg.max_ep_len
         self.n_rollout_threads = cfg.n_rollout_threads
@@ -48,6 +48,11 @@ class SharedReplayBuffer(object):
                 raise ValueError("compact buffer needs share_obs == concat(obs), n_pois and an expander "
                                  "(HipCoverageEnv.expand_obs)")
             self._expand = expander
+            # structured input (algos/algo_utils/structured.py): the policy consumes compact features of the state
+            # (dcc_obs_features) and observation rows are never built -- neither in the rollout nor in the update
+            self._featurize = featurizer
+            self.structured = featurizer is not None
+            self._feat_cache = {}
             self.obs = None
             self.obs_cur = z(E, N, D)         # observations of the newest slot only
             self._cur_slot = -1
@@ -57,6 +62,7 @@ class SharedReplayBuffer(object):
             self.state_done = torch.zeros(T + 1, E, n_pois, dtype=torch.uint8, device=self.device)
             self._chunk_obs = None
         else:
+            self.structured = False
             self.obs = z(T + 1, E, N, D)
         self._share_obs = None if (self._shared_is_view or self.compact) else z(T + 1, E, S)
         self.value_preds = z(T + 1, E, N, 1)
@@ -112,6 +118,28 @@ class SharedReplayBuffer(object):
             return self.obs_at(t).view(self.n_rollout_threads, -1)
         return self.share_obs_env[t]
 
+    def features_at(self, t):
+        """Compact policy-input features of slot t (structured mode): dict(head [E,N,HD], poi_feat [E,2M], stats)."""
+        return self._featurize(self.state_pos[t], self.state_vel[t], self.state_energy[t], self.state_done[t])
+
+    def features_rows(self, t0, t1):
+        """Features of slots t0..t1-1 flattened over (step, env); cached until the next rollout overwrites the state
+        (they do not depend on the parameters, so all PPO epochs share them)."""
+        key = (t0, t1)
+        f = self._feat_cache.get(key)
+        if f is None:
+            E, N = self.n_rollout_threads, self.num_agents
+            n = (t1 - t0) * E
+            f = self._feat_cache[key] = self._featurize(
+                self.state_pos[t0:t1].reshape(n, N, 2), self.state_vel[t0:t1].reshape(n, N, 2),
+                self.state_energy[t0:t1].reshape(n, -1), self.state_done[t0:t1].reshape(n, -1))
+        return f
+
+    def invalidate_features(self):
+        """Drop the cached per-chunk features (call whenever the state slots are about to be rewritten)."""
+        if self.compact:
+            self._feat_cache.clear()
+
     def obs_rows(self, t0, t1):
         """[(t1-t0), E, N, D] observations of slots t0..t1-1; compact: regenerated from state into a reused chunk."""
         if not self.compact:
@@ -131,10 +159,16 @@ class SharedReplayBuffer(object):
         E, N = self.n_rollout_threads, self.num_agents
         n = (t1 - t0) * E
         rows = lambda x: x[t0:t1].reshape(n * N, -1)
+        adv = torch.as_tensor(advantages).to(self.device, torch.float32)
+        if self.structured:
+            f = self.features_rows(t0, t1)
+            if not dedup_critic:
+                raise NotImplementedError("structured input evaluates the centralised critic once per env (dedup_critic)")
+            return (f, f, None, None, rows(self.actions), rows(self.value_preds), rows(self.returns),
+                    rows(self.masks), rows(self.active_masks), rows(self.action_log_probs), rows(adv), None)
         obs = self.obs_rows(t0, t1)
         so_env = obs.reshape(n, N * self.obs_dim) if (self._shared_is_view or self.compact) else self._share_obs[t0:t1].reshape(n, -1)
         so = so_env if dedup_critic else so_env.unsqueeze(1).expand(-1, N, -1).reshape(n * N, -1)
-        adv = torch.as_tensor(advantages).to(self.device, torch.float32)
         return (so, obs.reshape(n * N, -1), None, None, rows(self.actions), rows(self.value_preds), rows(self.returns),
                 rows(self.masks), rows(self.active_masks), rows(self.action_log_probs), rows(adv), None)
 

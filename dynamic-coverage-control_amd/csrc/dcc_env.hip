@@ -775,6 +775,67 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : 4)) void dcc_obs_expand_ker
     produce_obs<PPL, false, 0, 0>(p, st, reinterpret_cast<const double*>(apos), en, dmask, poi, lane);
 }
 
+// ---- kernel 4: compact policy-input features from compact state (dcc_obs_features) -------------------------------
+// The observation row of agent i is  [vel_i, pos_i, (pos_a - pos_i) a!=i | (poi_j - pos_i, energy_j, m_energy, done_j) j].
+// Its PoI block differs between the agents of an env only by the translation pos_i, so the first Linear layer of a
+// policy can be evaluated from (a) the 4 + 2(N-1) "head" columns per agent, (b) the 2M per-env PoI features
+// (energy, done) and (c) the LayerNorm moments of the full row -- ~1/37 of the row at 8 UAV x 64 PoI -- without the
+// row ever being written (algos/algo_utils/structured.py has the algebra).  One wavefront per state.
+struct FeatParams {
+    const double2* pos; const double2* vel; const float* energy; const uint8_t* done; const double2* poi;
+    float* head; float* poi_feat; double* stats;
+    int n, N, M; float m_energy;
+};
+
+__global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x * kWavesPerBlock + wid;
+    if (n >= p.n) return;
+    const int N = p.N, M = p.M, HD = 4 + 2 * (N - 1), D = HD + 5 * M;
+    double2 mp = make_double2(0.0, 0.0), mv = mp;
+    if (lane < N) { mp = p.pos[(size_t)n * N + lane]; mv = p.vel[(size_t)n * N + lane]; }
+    const float* en = p.energy + (size_t)n * M;
+    const uint8_t* dn = p.done + (size_t)n * M;
+    if (p.poi_feat) {
+        float* f = p.poi_feat + (size_t)n * 2 * M;
+        for (int j = lane; j < M; j += 64) { f[j] = en[j]; f[M + j] = dn[j] ? 1.f : 0.f; }
+    }
+    const double me = (double)p.m_energy;
+    for (int i = 0; i < N; ++i) {
+        const double px = readlane_f64(mp.x, i), py = readlane_f64(mp.y, i);
+        const float rx = (float)(mp.x - px), ry = (float)(mp.y - py);   // what the obs row holds for agent `lane`
+        const bool other = lane < N && lane != i;
+        const float v0 = (float)mv.x, v1 = (float)mv.y, p0 = (float)mp.x, p1 = (float)mp.y;
+        if (p.head) {
+            float* h = p.head + ((size_t)n * N + i) * HD;
+            if (lane == i) { h[0] = v0; h[1] = v1; h[2] = p0; h[3] = p1; }
+            if (other) { const int k = lane < i ? lane : lane - 1; h[4 + 2 * k] = rx; h[5 + 2 * k] = ry; }
+        }
+        if (!p.stats) continue;
+        // two-pass moments of the D float32 values of the row, accumulated in float64
+        double s = 0.0;
+        if (lane == i) s = ((double)v0 + (double)v1) + ((double)p0 + (double)p1);
+        if (other) s = (double)rx + (double)ry;
+        for (int j = lane; j < M; j += 64) {
+            const double2 q = p.poi[j];
+            s += (double)(float)(q.x - px) + (double)(float)(q.y - py) + (double)en[j] + me + (dn[j] ? 1.0 : 0.0);
+        }
+        const double mean = wave_sum_f64(s) / (double)D;
+        double m2 = 0.0;
+        auto sq = [mean](double x) { const double d = x - mean; return d * d; };
+        if (lane == i) m2 = sq((double)v0) + sq((double)v1) + sq((double)p0) + sq((double)p1);
+        if (other) m2 = sq((double)rx) + sq((double)ry);
+        for (int j = lane; j < M; j += 64) {
+            const double2 q = p.poi[j];
+            m2 += sq((double)(float)(q.x - px)) + sq((double)(float)(q.y - py)) + sq((double)en[j]) + sq(me) +
+                  sq(dn[j] ? 1.0 : 0.0);
+        }
+        m2 = wave_sum_f64(m2);
+        if (lane == 0) { p.stats[((size_t)n * N + i) * 2] = mean; p.stats[((size_t)n * N + i) * 2 + 1] = m2; }
+    }
+}
+
 // ---- kernel 2: role-specialised -- a PHYSICS wave and an OBSERVATION wave per workgroup --------------------
 // Measured on MI355X (tools/overlap_probe*.hip): when every wave alternates compute and its 10.8 KB of obs
 // stores, the compute overlaps only ~2/3 with the chip-wide store stream; waves that do nothing but stream
@@ -1286,6 +1347,26 @@ int dcc_obs_expand(dcc_env* e, int64_t n, const double* pos, const double* vel, 
     }
     const int grid = (int)((n + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), e->lds_bytes, reinterpret_cast<hipStream_t>(stream), p);
+    HIP_TRY(hipGetLastError());
+    return DCC_OK;
+}
+
+int dcc_obs_features(dcc_env* e, int64_t n, const double* pos, const double* vel, const float* energy,
+                     const uint8_t* done, float* head, float* poi_feat, double* stats, void* stream) {
+    if (!e) return fail(DCC_EINVAL, "dcc_obs_features: null env");
+    if (n < 1 || n > 0x7fffffffLL) return fail(DCC_EINVAL, "dcc_obs_features: n out of range");
+    if (!pos || !vel || !energy || !done) return fail(DCC_EINVAL, "dcc_obs_features: null state pointer");
+    if ((reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(vel)) & 15u)
+        return fail(DCC_EINVAL, "dcc_obs_features: pos / vel must be 16-byte aligned");
+    if (!head && !poi_feat && !stats) return DCC_OK;
+    DeviceGuard guard(e->device);
+    FeatParams p;
+    p.pos = reinterpret_cast<const double2*>(pos); p.vel = reinterpret_cast<const double2*>(vel);
+    p.energy = energy; p.done = done; p.poi = e->d_poi;
+    p.head = head; p.poi_feat = poi_feat; p.stats = stats;
+    p.n = (int)n; p.N = e->cfg.n_agents; p.M = e->cfg.n_pois; p.m_energy = (float)e->cfg.m_energy;
+    const int grid = (int)((n + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(dcc_obs_features_kernel, dim3(grid), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), p);
     HIP_TRY(hipGetLastError());
     return DCC_OK;
 }

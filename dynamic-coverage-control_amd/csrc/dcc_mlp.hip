@@ -1,0 +1,557 @@
+// dcc_mlp.hip -- fused element-wise stages of the MAPPO policy trunks (include/dcc_mlp.h).
+//
+// Layout: one wavefront owns a row of H activations at a time; lane l holds the VEC consecutive columns starting at
+// (v*64 + l)*VEC for v < VPL, so every global access of a wave is a run of 64*VEC consecutive floats (float4 per
+// lane when H % 4 == 0).  LayerNorm reductions are wave reductions; nothing but the parameter-gradient partial
+// sums leaves registers.  Waves walk rows (or envs) with a grid stride; each keeps private partial sums of the
+// parameter gradients in registers and writes them once to `workspace`; a second tiny kernel adds the partials in a
+// fixed order (no float atomics -> bit-reproducible updates, which the checkpoint/resume test relies on).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "dcc_mlp.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = 4;
+constexpr int kReluLnBlocks = 1024;   // 4096 waves: 16 per CU
+constexpr int kL1Blocks = 512;        // 2048 waves (the L1 backward keeps ~100 accumulators per lane)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int VEC>
+__device__ __forceinline__ void ld(const float* __restrict__ p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = *p;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void st(float* __restrict__ p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        *p = v[0];
+    }
+}
+
+// ReLU + LayerNorm statistics of one row held in a[VPL][VEC] (already ReLU'd, zeros in masked slots).
+template <int VEC, int VPL>
+__device__ __forceinline__ void row_stats(const float (&a)[VPL][VEC], const bool (&ok)[VPL], float invH, float eps,
+                                          float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s += a[v][j];
+    mean = wave_sum(s) * invH;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+        if (ok[v]) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { const float d = a[v][j] - mean; q += d * d; }
+        }
+    rstd = 1.0f / sqrtf(wave_sum(q) * invH + eps);
+}
+
+// ---- h = LayerNorm(ReLU(z)) -------------------------------------------------------------------------------------
+template <int VEC, int VPL>
+__global__ __launch_bounds__(kBlock) void relu_ln_fwd_k(const float* __restrict__ z, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ h, long long R, int H) {
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * kWavesPerBlock;
+    float g[VPL][VEC], b[VPL][VEC];
+    bool ok[VPL];
+    int cb[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        cb[v] = (v * 64 + lane) * VEC;
+        ok[v] = cb[v] < H;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { g[v][j] = 0.f; b[v][j] = 0.f; }
+        if (ok[v]) { ld<VEC>(gamma + cb[v], g[v]); ld<VEC>(beta + cb[v], b[v]); }
+    }
+    const float invH = 1.0f / (float)H;
+    for (long long r = gw; r < R; r += nw) {
+        float a[VPL][VEC];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a[v][j] = 0.f;
+            if (ok[v]) {
+                ld<VEC>(z + r * H + cb[v], a[v]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) a[v][j] = fmaxf(a[v][j], 0.f);
+            }
+        }
+        float mean, rstd;
+        row_stats<VEC, VPL>(a, ok, invH, eps, mean, rstd);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+            if (ok[v]) {
+                float o[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = (a[v][j] - mean) * rstd * g[v][j] + b[v][j];
+                st<VEC>(h + r * H + cb[v], o);
+            }
+    }
+}
+
+// LayerNorm + ReLU backward for one row: a = ReLU(z) values, dh the incoming gradient (overwritten by dz);
+// accumulates dgamma / dbeta partials.
+template <int VEC, int VPL>
+__device__ __forceinline__ void row_bwd(const float (&zr)[VPL][VEC], const float (&a)[VPL][VEC], float (&dh)[VPL][VEC],
+                                        const float (&g)[VPL][VEC], const bool (&ok)[VPL], float invH, float mean,
+                                        float rstd, float (&acc_g)[VPL][VEC], float (&acc_b)[VPL][VEC]) {
+    float s1 = 0.f, s2 = 0.f;
+    float xh[VPL][VEC];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            xh[v][j] = ok[v] ? (a[v][j] - mean) * rstd : 0.f;
+            acc_g[v][j] += dh[v][j] * xh[v][j];
+            acc_b[v][j] += dh[v][j];
+            const float dx = dh[v][j] * g[v][j];
+            dh[v][j] = dx;
+            s1 += dx;
+            s2 += dx * xh[v][j];
+        }
+    const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            dh[v][j] = (zr[v][j] > 0.f) ? rstd * (dh[v][j] - m1 - xh[v][j] * m2) : 0.f;
+}
+
+template <int VEC, int VPL>
+__global__ __launch_bounds__(kBlock) void relu_ln_bwd_k(const float* __restrict__ z, const float* __restrict__ gamma,
+                                                        const float* __restrict__ dh, float eps,
+                                                        float* __restrict__ dz, float* __restrict__ ws, long long R,
+                                                        int H) {
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * kWavesPerBlock;
+    float g[VPL][VEC], acc_g[VPL][VEC], acc_b[VPL][VEC];
+    bool ok[VPL];
+    int cb[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        cb[v] = (v * 64 + lane) * VEC;
+        ok[v] = cb[v] < H;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { g[v][j] = 0.f; acc_g[v][j] = 0.f; acc_b[v][j] = 0.f; }
+        if (ok[v]) ld<VEC>(gamma + cb[v], g[v]);
+    }
+    const float invH = 1.0f / (float)H;
+    for (long long r = gw; r < R; r += nw) {
+        float zr[VPL][VEC], a[VPL][VEC], d[VPL][VEC];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { zr[v][j] = 0.f; d[v][j] = 0.f; }
+            if (ok[v]) { ld<VEC>(z + r * H + cb[v], zr[v]); ld<VEC>(dh + r * H + cb[v], d[v]); }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a[v][j] = fmaxf(zr[v][j], 0.f);
+        }
+        float mean, rstd;
+        row_stats<VEC, VPL>(a, ok, invH, eps, mean, rstd);
+        row_bwd<VEC, VPL>(zr, a, d, g, ok, invH, mean, rstd, acc_g, acc_b);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+            if (ok[v]) st<VEC>(dz + r * H + cb[v], d[v]);
+    }
+    float* w = ws + gw * 2 * H;   // per-wave partials: [dgamma | dbeta]
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+        if (ok[v]) { st<VEC>(w + cb[v], acc_g[v]); st<VEC>(w + H + cb[v], acc_b[v]); }
+}
+
+// out[p] = sum over the nw per-wave partial vectors (fixed order).
+__global__ __launch_bounds__(kBlock) void reduce_partials_k(const float* __restrict__ ws, long long nw, int P,
+                                                            float* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long long w = 0;
+    for (; w + 3 < nw; w += 4) {
+        s0 += ws[w * P + p]; s1 += ws[(w + 1) * P + p]; s2 += ws[(w + 2) * P + p]; s3 += ws[(w + 3) * P + p];
+    }
+    for (; w < nw; ++w) s0 += ws[w * P + p];
+    out[p] = (s0 + s1) + (s2 + s3);
+}
+
+// ---- actor first block from compact features -------------------------------------------------------------------
+// z[r,c] = rstd_in[r] * (sum_k head[r,k] Wh[c,k] + G[e,c] - mean_in[r] s[c]) + cb[c];   h = LayerNorm(ReLU(z))
+// One wave per env: G[e] is loaded once for its N agent rows and (backward) dG[e] is summed in registers.
+// Wh^T lives in LDS as Wt[k][c] (conflict-free float4 reads, shared by the block's waves).
+template <int VEC, int VPL>
+__device__ __forceinline__ void l1_row_z(const float* __restrict__ Wt, int H, int HD, float hv, float mean_in,
+                                         float rstd_in, const float (&Gv)[VPL][VEC], const float (&sv)[VPL][VEC],
+                                         const float (&cv)[VPL][VEC], const int (&cb)[VPL], const bool (&ok)[VPL],
+                                         float (&zr)[VPL][VEC]) {
+    float u[VPL][VEC];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) u[v][j] = 0.f;
+    for (int k = 0; k < HD; ++k) {
+        const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), k));
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+            if (ok[v]) {
+                float w[VEC];
+                ld<VEC>(Wt + k * H + cb[v], w);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) u[v][j] += x * w[j];
+            }
+    }
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            zr[v][j] = ok[v] ? rstd_in * (u[v][j] + Gv[v][j] - mean_in * sv[v][j]) + cv[v][j] : 0.f;
+}
+
+__device__ __forceinline__ void in_stats(const double* __restrict__ stats, long long r, int D, float eps_in,
+                                         float& mean_in, float& rstd_in) {
+    mean_in = 0.f; rstd_in = 1.f;
+    if (stats) {
+        const double m = stats[2 * r], m2 = stats[2 * r + 1];
+        mean_in = (float)m;
+        rstd_in = (float)(1.0 / sqrt(m2 / (double)D + (double)eps_in));
+    }
+}
+
+template <int VEC, int VPL>
+__global__ __launch_bounds__(kBlock) void actor_l1_fwd_k(const float* __restrict__ head, const float* __restrict__ G,
+                                                         const double* __restrict__ stats,
+                                                         const float* __restrict__ Wh, const float* __restrict__ s,
+                                                         const float* __restrict__ c, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps_in, float eps_ln,
+                                                         int D, float* __restrict__ h, long long n, int N, int HD,
+                                                         int H) {
+    extern __shared__ __attribute__((aligned(16))) float Wt[];   // [HD][H]
+    for (int i = threadIdx.x; i < HD * H; i += kBlock) { const int k = i / H, cc = i - k * H; Wt[i] = Wh[cc * HD + k]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * kWavesPerBlock;
+    float g[VPL][VEC], b[VPL][VEC], sv[VPL][VEC], cv[VPL][VEC];
+    bool ok[VPL];
+    int cb[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        cb[v] = (v * 64 + lane) * VEC;
+        ok[v] = cb[v] < H;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { g[v][j] = 0.f; b[v][j] = 0.f; sv[v][j] = 0.f; cv[v][j] = 0.f; }
+        if (ok[v]) { ld<VEC>(gamma + cb[v], g[v]); ld<VEC>(beta + cb[v], b[v]); ld<VEC>(s + cb[v], sv[v]); ld<VEC>(c + cb[v], cv[v]); }
+    }
+    const float invH = 1.0f / (float)H;
+    for (long long e = gw; e < n; e += nw) {
+        float Gv[VPL][VEC];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) Gv[v][j] = 0.f;
+            if (ok[v]) ld<VEC>(G + e * H + cb[v], Gv[v]);
+        }
+        for (int i = 0; i < N; ++i) {
+            const long long r = e * N + i;
+            const float hv = lane < HD ? head[r * HD + lane] : 0.f;
+            float mean_in, rstd_in;
+            in_stats(stats, r, D, eps_in, mean_in, rstd_in);
+            float a[VPL][VEC];
+            l1_row_z<VEC, VPL>(Wt, H, HD, hv, mean_in, rstd_in, Gv, sv, cv, cb, ok, a);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) a[v][j] = fmaxf(a[v][j], 0.f);
+            float mean, rstd;
+            row_stats<VEC, VPL>(a, ok, invH, eps_ln, mean, rstd);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+                if (ok[v]) {
+                    float o[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) o[j] = (a[v][j] - mean) * rstd * g[v][j] + b[v][j];
+                    st<VEC>(h + r * H + cb[v], o);
+                }
+        }
+    }
+}
+
+// per-wave partial vector of the L1 backward: [dWt (HDP*H) | ds (H) | dc (H) | dgamma (H) | dbeta (H)]
+template <int VEC, int VPL, int HDP>
+__global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict__ head, const float* __restrict__ G,
+                                                         const double* __restrict__ stats,
+                                                         const float* __restrict__ Wh, const float* __restrict__ s,
+                                                         const float* __restrict__ c, const float* __restrict__ gamma,
+                                                         const float* __restrict__ dh, float eps_in, float eps_ln,
+                                                         int D, float* __restrict__ dG, float* __restrict__ ws,
+                                                         long long n, int N, int HD, int H) {
+    extern __shared__ __attribute__((aligned(16))) float Wt[];   // [HD][H]
+    for (int i = threadIdx.x; i < HD * H; i += kBlock) { const int k = i / H, cc = i - k * H; Wt[i] = Wh[cc * HD + k]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * kWavesPerBlock;
+    float g[VPL][VEC], sv[VPL][VEC], cv[VPL][VEC];
+    float acc_g[VPL][VEC], acc_b[VPL][VEC], acc_s[VPL][VEC], acc_c[VPL][VEC], acc_w[HDP][VPL][VEC];
+    bool ok[VPL];
+    int cb[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        cb[v] = (v * 64 + lane) * VEC;
+        ok[v] = cb[v] < H;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            g[v][j] = 0.f; sv[v][j] = 0.f; cv[v][j] = 0.f;
+            acc_g[v][j] = 0.f; acc_b[v][j] = 0.f; acc_s[v][j] = 0.f; acc_c[v][j] = 0.f;
+        }
+        if (ok[v]) { ld<VEC>(gamma + cb[v], g[v]); ld<VEC>(s + cb[v], sv[v]); ld<VEC>(c + cb[v], cv[v]); }
+    }
+#pragma unroll
+    for (int k = 0; k < HDP; ++k)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc_w[k][v][j] = 0.f;
+    const float invH = 1.0f / (float)H;
+    for (long long e = gw; e < n; e += nw) {
+        float Gv[VPL][VEC], dGv[VPL][VEC];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { Gv[v][j] = 0.f; dGv[v][j] = 0.f; }
+            if (ok[v]) ld<VEC>(G + e * H + cb[v], Gv[v]);
+        }
+        for (int i = 0; i < N; ++i) {
+            const long long r = e * N + i;
+            const float hv = lane < HD ? head[r * HD + lane] : 0.f;
+            float mean_in, rstd_in;
+            in_stats(stats, r, D, eps_in, mean_in, rstd_in);
+            float zr[VPL][VEC], a[VPL][VEC], d[VPL][VEC];
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) d[v][j] = 0.f;
+                if (ok[v]) ld<VEC>(dh + r * H + cb[v], d[v]);
+            }
+            l1_row_z<VEC, VPL>(Wt, H, HD, hv, mean_in, rstd_in, Gv, sv, cv, cb, ok, zr);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) a[v][j] = fmaxf(zr[v][j], 0.f);
+            float mean, rstd;
+            row_stats<VEC, VPL>(a, ok, invH, eps_ln, mean, rstd);
+            row_bwd<VEC, VPL>(zr, a, d, g, ok, invH, mean, rstd, acc_g, acc_b);   // d = dL/dz
+            float q[VPL][VEC];
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    q[v][j] = rstd_in * d[v][j];
+                    dGv[v][j] += q[v][j];
+                    acc_s[v][j] -= mean_in * q[v][j];
+                    acc_c[v][j] += d[v][j];
+                }
+#pragma unroll
+            for (int k = 0; k < HDP; ++k) {
+                if (k < HD) {
+                    const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), k));
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) acc_w[k][v][j] += q[v][j] * x;
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+            if (ok[v]) st<VEC>(dG + e * H + cb[v], dGv[v]);
+    }
+    const int P = (HDP + 4) * H;
+    float* w = ws + gw * P;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+        if (ok[v]) {
+#pragma unroll
+            for (int k = 0; k < HDP; ++k) st<VEC>(w + k * H + cb[v], acc_w[k][v]);
+            st<VEC>(w + (HDP + 0) * H + cb[v], acc_s[v]);
+            st<VEC>(w + (HDP + 1) * H + cb[v], acc_c[v]);
+            st<VEC>(w + (HDP + 2) * H + cb[v], acc_g[v]);
+            st<VEC>(w + (HDP + 3) * H + cb[v], acc_b[v]);
+        }
+}
+
+// partial layout [k][c] -> dWh [c][k], plus the four H-vectors
+__global__ __launch_bounds__(kBlock) void l1_reduce_k(const float* __restrict__ ws, long long nw, int HDP, int HD, int H,
+                                                      float* __restrict__ dWh, float* __restrict__ ds,
+                                                      float* __restrict__ dc, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta) {
+    const int P = (HDP + 4) * H;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int k = p / H, cc = p - k * H;
+    if (k < HDP && k >= HD) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long long w = 0;
+    for (; w + 3 < nw; w += 4) {
+        s0 += ws[w * P + p]; s1 += ws[(w + 1) * P + p]; s2 += ws[(w + 2) * P + p]; s3 += ws[(w + 3) * P + p];
+    }
+    for (; w < nw; ++w) s0 += ws[w * P + p];
+    const float t = (s0 + s1) + (s2 + s3);
+    if (k < HDP) dWh[cc * HD + k] = t;
+    else if (k == HDP) ds[cc] = t;
+    else if (k == HDP + 1) dc[cc] = t;
+    else if (k == HDP + 2) dgamma[cc] = t;
+    else dbeta[cc] = t;
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------
+struct Shape { int vec, vpl; };
+bool pick_shape(int H, Shape& sh) {
+    if (H < 1) return false;
+    if (H % 4 == 0 && H <= 256) { sh = {4, 1}; return true; }
+    if (H % 4 == 0 && H <= 512) { sh = {4, 2}; return true; }
+    if (H <= 64) { sh = {1, 1}; return true; }
+    if (H <= 128) { sh = {1, 2}; return true; }
+    return false;
+}
+int pad_hd(int HD) {
+    if (HD <= 0) return 0;
+    for (int p : {8, 16, 24, 40})
+        if (HD <= p) return p;
+    return -1;
+}
+long long waves_for(long long units, int blocks) {
+    long long b = (units + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (b > blocks) b = blocks;
+    if (b < 1) b = 1;
+    return b;
+}
+
+#define LAUNCH_SHAPE(KERNEL, grid, lds, ...)                                                                       \
+    do {                                                                                                           \
+        if (sh.vec == 4 && sh.vpl == 1) hipLaunchKernelGGL((KERNEL<4, 1>), dim3(grid), dim3(kBlock), lds, st_, __VA_ARGS__); \
+        else if (sh.vec == 4) hipLaunchKernelGGL((KERNEL<4, 2>), dim3(grid), dim3(kBlock), lds, st_, __VA_ARGS__);  \
+        else if (sh.vpl == 1) hipLaunchKernelGGL((KERNEL<1, 1>), dim3(grid), dim3(kBlock), lds, st_, __VA_ARGS__);  \
+        else hipLaunchKernelGGL((KERNEL<1, 2>), dim3(grid), dim3(kBlock), lds, st_, __VA_ARGS__);                   \
+    } while (0)
+
+template <int HDP, typename... A>
+void launch_l1_bwd(const Shape& sh, int grid, size_t lds, hipStream_t st_, A... a) {
+    if (sh.vec == 4 && sh.vpl == 1) hipLaunchKernelGGL((actor_l1_bwd_k<4, 1, HDP>), dim3(grid), dim3(kBlock), lds, st_, a...);
+    else if (sh.vec == 4) hipLaunchKernelGGL((actor_l1_bwd_k<4, 2, HDP>), dim3(grid), dim3(kBlock), lds, st_, a...);
+    else if (sh.vpl == 1) hipLaunchKernelGGL((actor_l1_bwd_k<1, 1, HDP>), dim3(grid), dim3(kBlock), lds, st_, a...);
+    else hipLaunchKernelGGL((actor_l1_bwd_k<1, 2, HDP>), dim3(grid), dim3(kBlock), lds, st_, a...);
+}
+
+constexpr int kEINVAL = -1, kEHIP = -2, kEUNSUPPORTED = -4;
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+DCC_API int64_t dcc_mlp_workspace_floats(int32_t H, int32_t HD) {
+    Shape sh;
+    if (!pick_shape(H, sh)) return 0;
+    const int hdp = pad_hd(HD);
+    if (hdp < 0) return 0;
+    const int64_t a = (int64_t)kReluLnBlocks * kWavesPerBlock * 2 * H;
+    const int64_t b = HD > 0 ? (int64_t)kL1Blocks * kWavesPerBlock * (hdp + 4) * H : 0;
+    return a > b ? a : b;
+}
+
+DCC_API int dcc_relu_ln_fwd(const float* z, const float* gamma, const float* beta, float eps, float* h, int64_t R,
+                            int32_t H, void* stream) {
+    if (!z || !gamma || !beta || !h || R < 0) return kEINVAL;
+    Shape sh;
+    if (!pick_shape(H, sh)) return kEUNSUPPORTED;
+    if (sh.vec == 4 && !(aligned16(z) && aligned16(h) && aligned16(gamma) && aligned16(beta))) return kEINVAL;
+    if (R == 0) return 0;
+    hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
+    const int grid = (int)waves_for(R, kReluLnBlocks);
+    LAUNCH_SHAPE(relu_ln_fwd_k, grid, 0, z, gamma, beta, eps, h, (long long)R, (int)H);
+    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+}
+
+DCC_API int dcc_relu_ln_bwd(const float* z, const float* gamma, const float* dh, float eps, float* dz, float* dgamma,
+                            float* dbeta, float* workspace, int64_t R, int32_t H, void* stream) {
+    if (!z || !gamma || !dh || !dz || !dgamma || !dbeta || !workspace || R < 1) return kEINVAL;
+    if (dbeta != dgamma + H) return kEINVAL;   // [dgamma | dbeta] must be one contiguous [2,H] array
+    Shape sh;
+    if (!pick_shape(H, sh)) return kEUNSUPPORTED;
+    if (sh.vec == 4 && !(aligned16(z) && aligned16(dh) && aligned16(dz) && aligned16(gamma) && aligned16(workspace)))
+        return kEINVAL;
+    hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
+    const int grid = (int)waves_for(R, kReluLnBlocks);
+    LAUNCH_SHAPE(relu_ln_bwd_k, grid, 0, z, gamma, dh, eps, dz, workspace, (long long)R, (int)H);
+    const int P = 2 * H;
+    hipLaunchKernelGGL(reduce_partials_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace,
+                       (long long)grid * kWavesPerBlock, P, dgamma);
+    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+}
+
+DCC_API int dcc_actor_l1_fwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
+                             const float* c, const float* gamma, const float* beta, float eps_in, float eps_ln,
+                             int32_t D, float* h, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
+    if (!head || !G || !Wh || !s || !c || !gamma || !beta || !h || n < 1 || N < 1 || D < 1) return kEINVAL;
+    Shape sh;
+    if (!pick_shape(H, sh) || HD < 1 || HD > 64 || pad_hd(HD) < 0) return kEUNSUPPORTED;
+    const size_t lds = (size_t)HD * H * sizeof(float);
+    if (lds > 64 * 1024) return kEUNSUPPORTED;
+    if (sh.vec == 4 && !(aligned16(G) && aligned16(h) && aligned16(gamma) && aligned16(beta) && aligned16(s) && aligned16(c)))
+        return kEINVAL;
+    hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
+    const int grid = (int)waves_for(n, kL1Blocks * 2);
+    LAUNCH_SHAPE(actor_l1_fwd_k, grid, lds, head, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, (int)D, h,
+                 (long long)n, (int)N, (int)HD, (int)H);
+    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+}
+
+DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
+                             const float* c, const float* gamma, const float* dh, float eps_in, float eps_ln, int32_t D,
+                             float* dG, float* dWh, float* ds, float* dc, float* dgamma, float* dbeta, float* workspace,
+                             int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
+    if (!head || !G || !Wh || !s || !c || !gamma || !dh || !dG || !dWh || !ds || !dc || !dgamma || !dbeta ||
+        !workspace || n < 1 || N < 1 || D < 1)
+        return kEINVAL;
+    Shape sh;
+    const int hdp = pad_hd(HD);
+    if (!pick_shape(H, sh) || HD < 1 || HD > 64 || hdp < 0) return kEUNSUPPORTED;
+    const size_t lds = (size_t)HD * H * sizeof(float);
+    if (lds > 64 * 1024) return kEUNSUPPORTED;
+    if (sh.vec == 4 && !(aligned16(G) && aligned16(dh) && aligned16(dG) && aligned16(gamma) && aligned16(s) &&
+                         aligned16(c) && aligned16(workspace)))
+        return kEINVAL;
+    hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
+    const int grid = (int)waves_for(n, kL1Blocks);
+    switch (hdp) {
+        case 8: launch_l1_bwd<8>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+        case 16: launch_l1_bwd<16>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+        case 24: launch_l1_bwd<24>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+        default: launch_l1_bwd<40>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+    }
+    const int P = (hdp + 4) * H;
+    hipLaunchKernelGGL(l1_reduce_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace,
+                       (long long)grid * kWavesPerBlock, hdp, (int)HD, (int)H, dWh, ds, dc, dgamma, dbeta);
+    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+}
+
+}  // extern "C"

@@ -42,7 +42,8 @@ class EnvOut(ctypes.Structure):
 
 EXPORTS = ["dcc_obs_expand", "dcc_gae_compute", "dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
            "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout", "dcc_env_get_state",
-           "dcc_env_set_state", "dcc_env_bytes_per_step"]
+           "dcc_env_set_state", "dcc_env_bytes_per_step", "dcc_obs_features",
+           "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd"]
 
 _lib = None
 
@@ -75,6 +76,14 @@ def load_library(path=None):
     L.dcc_gae_compute.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, ctypes.c_int32,
                                   ctypes.c_int64, _vp]
     L.dcc_obs_expand.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.dcc_obs_features.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    f32, i32, i64 = ctypes.c_float, ctypes.c_int32, ctypes.c_int64
+    L.dcc_relu_ln_fwd.argtypes = [_vp, _vp, _vp, f32, _vp, i64, i32, _vp]
+    L.dcc_relu_ln_bwd.argtypes = [_vp, _vp, _vp, f32, _vp, _vp, _vp, _vp, i64, i32, _vp]
+    L.dcc_mlp_workspace_floats.argtypes = [i32, i32]
+    L.dcc_mlp_workspace_floats.restype = i64
+    L.dcc_actor_l1_fwd.argtypes = [_vp] * 8 + [f32, f32, i32, _vp, i64, i32, i32, i32, _vp]
+    L.dcc_actor_l1_bwd.argtypes = [_vp] * 8 + [f32, f32, i32] + [_vp] * 7 + [i64, i32, i32, i32, _vp]
     if L.dcc_abi_version() != 2:
         raise DccError("libdcc_hip.so ABI version %d != 2" % L.dcc_abi_version())
     _lib = L
@@ -125,6 +134,7 @@ class HipCoverageEnv:
         self.E, self.N, self.M = n_envs, n_agents, n_pois
         self.D = self.lib.dcc_env_obs_dim(h)
         self.poi = poi
+        self.m_energy = float(cfg.m_energy)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -175,6 +185,30 @@ class HipCoverageEnv:
             _check(self.lib.dcc_obs_expand(self._h, n, _ptr(pos), _ptr(vel), _ptr(energy), _ptr(done), _ptr(obs), _stream()),
                    "dcc_obs_expand")
         return obs
+
+    def obs_features(self, pos, vel, energy, done, out=None):
+        """Compact policy-input features of n states (include/dcc_env.h: dcc_obs_features):
+        dict(head [n,N,4+2(N-1)] f32, poi_feat [n,2M] f32, stats [n,N,2] f64 = (mean, sum sq. dev.) of each obs row)."""
+        n = pos.shape[0]
+        want = ((pos, (n, self.N, 2), torch.float64), (vel, (n, self.N, 2), torch.float64),
+                (energy, (n, self.M), torch.float32), (done, (n, self.M), torch.uint8))
+        for t, shape, dt in want:
+            if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("obs_features: need contiguous %s %s on %s" % (shape, dt, self.device))
+        HD = 4 + 2 * (self.N - 1)
+        shapes = dict(head=((n, self.N, HD), torch.float32), poi_feat=((n, 2 * self.M), torch.float32),
+                      stats=((n, self.N, 2), torch.float64))
+        if out is None:
+            out = {k: torch.empty(sh, dtype=dt, device=self.device) for k, (sh, dt) in shapes.items()}
+        for k, (sh, dt) in shapes.items():
+            t = out.get(k)
+            if t is not None and (tuple(t.shape) != sh or t.dtype != dt or not t.is_contiguous()):
+                raise ValueError("obs_features: output %r must be contiguous %s %s" % (k, sh, dt))
+        with torch.cuda.device(self.device):
+            _check(self.lib.dcc_obs_features(self._h, n, _ptr(pos), _ptr(vel), _ptr(energy), _ptr(done),
+                                             _ptr(out.get("head")), _ptr(out.get("poi_feat")), _ptr(out.get("stats")),
+                                             _stream()), "dcc_obs_features")
+        return out
 
     def _out_struct(self, out, K=None):
         # the same output tensors are passed step after step: validate and build the C struct once
@@ -294,3 +328,67 @@ def gae_compute(rewards, value_preds, masks, denorm, gamma, gae_lambda, returns,
     if rc != 0:
         raise DccError("dcc_gae_compute failed (%d)" % rc)
     return returns
+
+
+# ---- fused element-wise stages of the policy trunks (include/dcc_mlp.h) --------------------------------------------
+def mlp_fused_supported(H, HD=0):
+    """True when libdcc_hip.so has a compiled variant for hidden width H (and head width HD for the actor L1)."""
+    return load_library().dcc_mlp_workspace_floats(int(H), int(HD)) > 0
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+        raise ValueError("%s must be a contiguous float32 device tensor" % name)
+    return t
+
+
+def relu_ln_fwd(z, gamma, beta, eps):
+    R, H = z.shape
+    h = torch.empty_like(_f32c(z, "z"))
+    with torch.cuda.device(z.device):
+        _check(load_library().dcc_relu_ln_fwd(_ptr(z), _ptr(_f32c(gamma, "gamma")), _ptr(_f32c(beta, "beta")), eps, _ptr(h),
+                                              R, H, _stream()), "dcc_relu_ln_fwd")
+    return h
+
+
+def relu_ln_bwd(z, gamma, dh, eps):
+    R, H = z.shape
+    L = load_library()
+    dz = torch.empty_like(_f32c(z, "z"))
+    dgb = torch.empty((2, H), dtype=torch.float32, device=z.device)
+    ws = torch.empty(L.dcc_mlp_workspace_floats(H, 0), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        _check(L.dcc_relu_ln_bwd(_ptr(z), _ptr(_f32c(gamma, "gamma")), _ptr(_f32c(dh, "dh")), eps, _ptr(dz), _ptr(dgb[0]),
+                                 _ptr(dgb[1]), _ptr(ws), R, H, _stream()), "dcc_relu_ln_bwd")
+    return dz, dgb[0], dgb[1]
+
+
+def actor_l1_fwd(head, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, D):
+    n, N, HD = head.shape
+    H = G.shape[1]
+    h = torch.empty((n * N, H), dtype=torch.float32, device=head.device)
+    for t, nm in ((head, "head"), (G, "G"), (Wh, "Wh"), (s, "s"), (c, "c"), (gamma, "gamma"), (beta, "beta")):
+        _f32c(t, nm)
+    if stats is not None and (stats.dtype != torch.float64 or not stats.is_contiguous()):
+        raise ValueError("stats must be contiguous float64")
+    with torch.cuda.device(head.device):
+        _check(load_library().dcc_actor_l1_fwd(_ptr(head), _ptr(G), _ptr(stats), _ptr(Wh), _ptr(s), _ptr(c), _ptr(gamma),
+                                               _ptr(beta), eps_in, eps_ln, D, _ptr(h), n, N, HD, H, _stream()),
+               "dcc_actor_l1_fwd")
+    return h
+
+
+def actor_l1_bwd(head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, D):
+    n, N, HD = head.shape
+    H = G.shape[1]
+    L = load_library()
+    dev = head.device
+    dG = torch.empty_like(G)
+    dWh = torch.empty((H, HD), dtype=torch.float32, device=dev)
+    vecs = torch.empty((4, H), dtype=torch.float32, device=dev)     # ds, dc, dgamma, dbeta
+    ws = torch.empty(L.dcc_mlp_workspace_floats(H, HD), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(L.dcc_actor_l1_bwd(_ptr(head), _ptr(G), _ptr(stats), _ptr(Wh), _ptr(s), _ptr(c), _ptr(gamma),
+                                  _ptr(_f32c(dh, "dh")), eps_in, eps_ln, D, _ptr(dG), _ptr(dWh), _ptr(vecs[0]), _ptr(vecs[1]),
+                                  _ptr(vecs[2]), _ptr(vecs[3]), _ptr(ws), n, N, HD, H, _stream()), "dcc_actor_l1_bwd")
+    return dG, dWh, vecs[0], vecs[1], vecs[2], vecs[3]

@@ -60,6 +60,7 @@ class HipCoverageVecEnv:
         self.n_envs, self.n_agents, self.n_pois = int(n_envs), int(num_agents), int(num_pois)
         self.max_ep_len = max_ep_len
         poi = load_pois(self.n_pois) if poi_xy is None else np.asarray(poi_xy, np.float64)
+        self.poi_xy = poi
         self.env = dcc_hip.HipCoverageEnv(self.n_envs, self.n_agents, self.n_pois, poi, r_cover, r_comm, comm_r_scale,
                                           comm_force_scale, device=device, **consts)
         self.device = self.env.device
@@ -79,7 +80,7 @@ class HipCoverageVecEnv:
     def reset_device(self, obs_out=None):
         return self.env.reset(obs_out)
 
-    def step_device(self, actions, obs_out=None, out=None, extra_out=None):
+    def step_device(self, actions, obs_out=None, out=None, extra_out=None, want_obs=True):
         """actions: [E,N,2] float32/float64 tensor on the device.  Returns the dict of output tensors
         (obs, reward [E], done [E] u8, connect, connect_s, coverage [E], assign [E,M]).  `obs_out` lets
         the caller name the destination of the observations (e.g. a rollout-buffer slot).  The small
@@ -89,8 +90,9 @@ class HipCoverageVecEnv:
             if self._out is None:
                 self._out = self.env.alloc_out(obs=False)
             out = dict(self._out)
-            out["obs"] = obs_out if obs_out is not None else torch.empty(
-                (self.n_envs, self.n_agents, self.obs_dim), dtype=torch.float32, device=self.device)
+            if want_obs:     # want_obs=False: the caller consumes the compact state outputs instead of rows
+                out["obs"] = obs_out if obs_out is not None else torch.empty(
+                    (self.n_envs, self.n_agents, self.obs_dim), dtype=torch.float32, device=self.device)
             if extra_out:
                 out.update(extra_out)
         return self.env.step(actions, out)

@@ -68,6 +68,12 @@ class Learner:
         from algos.mappo import MAPPOPolicy, MAPPOTrainer
         self.policy = MAPPOPolicy(self.cfg, self.train_envs.observation_space[0], self.share_observation_space,
                                   self.train_envs.action_space[0])
+        if getattr(self.cfg, "structured_input", False):
+            if not self.cfg.dedup_critic:
+                raise ValueError("structured_input needs dedup_critic: true")
+            from algos.algo_utils.structured import ObsLayout
+            env = self.train_envs
+            self.policy.enable_structured_input(ObsLayout(env.n_agents, env.n_pois, env.poi_xy, env.env.m_energy))
         self.policy.broadcast_parameters(0)
         self.trainer = MAPPOTrainer(cfg=self.cfg, policy=self.policy)
 
@@ -107,9 +113,11 @@ class Learner:
     def _make_buffer(self, envs):
         bcfg = copy.deepcopy(self.cfg)
         bcfg.n_rollout_threads = envs.n_envs
-        compact = bool(getattr(self.cfg, "compact_obs", False))
+        structured = bool(getattr(self.cfg, "structured_input", False))
+        compact = bool(getattr(self.cfg, "compact_obs", False)) or structured
         return SharedReplayBuffer(bcfg, envs.observation_space[0], envs.share_observation_space[0], envs.action_space[0],
-                                  compact=compact, n_pois=envs.n_pois, expander=envs.env.expand_obs if compact else None)
+                                  compact=compact, n_pois=envs.n_pois, expander=envs.env.expand_obs if compact else None,
+                                  featurizer=envs.env.obs_features if structured else None)
 
     # ---- training loop (learner.py:132-175) ---------------------------------------------------------
     def train(self):
@@ -143,8 +151,8 @@ class Learner:
         cov_max = torch.zeros(r_envs.n_envs, dtype=torch.float32, device=ptu.device)
         for cur_step in range(self.max_ep_len):
             values, actions, action_log_probs = self.collect(cur_step, r_buffer)
-            out = r_envs.step_device(actions, obs_out=r_buffer.obs_slot(cur_step + 1),
-                                     extra_out=r_buffer.state_slot(cur_step + 1))
+            out = r_envs.step_device(actions, obs_out=None if r_buffer.structured else r_buffer.obs_slot(cur_step + 1),
+                                     extra_out=r_buffer.state_slot(cur_step + 1), want_obs=not r_buffer.structured)
             self.insert((out, values, actions, action_log_probs), r_buffer)
             rew_sum += out["reward"].double().mean()
             cov_max = torch.maximum(cov_max, out["coverage"])
@@ -156,6 +164,7 @@ class Learner:
         if is_render:
             raise NotImplementedError("rendering is out of scope (no display on a GPU node)")
         key = id(r_buffer)
+        r_buffer.invalidate_features()     # host-side cache: must also be dropped when the rollout is a graph replay
         if self.use_hip_graph and key in self._graphs:
             graph, stats = self._graphs[key]
             graph.replay()
@@ -195,6 +204,12 @@ class Learner:
         """policy forward on the E*N agent rows, critic on the E env rows (learner.py:227-252)."""
         self.trainer.prep_rollout()
         E, N = r_buffer.n_rollout_threads, self.n_agents
+        if r_buffer.structured:     # compact features of the current state: no observation rows anywhere
+            feats = r_buffer.features_at(cur_step)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.trainer.amp_bf16):
+                actions, logp, _ = self.policy.actor(feats)
+                values = self.policy.critic(feats)[0].view(E, 1, 1).expand(E, N, 1)
+            return values.float(), actions.float().view(E, N, -1).contiguous(), logp.float().view(E, N, 1)
         obs = r_buffer.obs_at(cur_step).view(E * N, -1)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.trainer.amp_bf16):
             actions, logp, _ = self.policy.actor(obs)
@@ -218,7 +233,9 @@ class Learner:
         """bootstrap value + GAE (learner.py:278-287 -> HIP scan)."""
         self.trainer.prep_rollout()
         E, N = r_buffer.n_rollout_threads, self.n_agents
-        next_values = self.policy.critic(r_buffer.share_obs_env_at(r_buffer.episode_length))[0].view(E, 1, 1).expand(E, N, 1)
+        last = r_buffer.episode_length
+        cent = r_buffer.features_at(last) if r_buffer.structured else r_buffer.share_obs_env_at(last)
+        next_values = self.policy.critic(cent)[0].view(E, 1, 1).expand(E, N, 1)
         r_buffer.compute_returns(next_values, self.trainer.value_normalizer)
 
     # ---- update (learner.py:292-300) ---------------------------------------------------------------------

@@ -137,6 +137,17 @@ DCC_API int dcc_env_set_state(dcc_env* env, const double* pos, const double* vel
 DCC_API int dcc_obs_expand(dcc_env* env, int64_t n, const double* pos, const double* vel, const float* energy,
                            const uint8_t* done, float* obs, void* stream);
 
+/* Compact policy-input features of n states (same state layout as dcc_obs_expand); any output may be NULL:
+ *   head     [n,N,4+2(N-1)] float32  the first columns of every observation row (own vel, own pos, other UAVs'
+ *                                    relative positions; coverage.py:100-104), bit-identical to obs[..., :4+2(N-1)]
+ *   poi_feat [n,2M]         float32  PoI energies then PoI done flags (the obs columns that do not depend on the agent)
+ *   stats    [n,N,2]        float64  (mean, sum of squared deviations) of the D float32 values of every row, i.e. the
+ *                                    moments an input LayerNorm over the row needs (algos/algo_utils/mlp.py:45-49)
+ * With them the first Linear layer after the input LayerNorm is evaluated without materialising the rows
+ * (dynamic-coverage-control_amd/algos/algo_utils/structured.py). */
+DCC_API int dcc_obs_features(dcc_env* env, int64_t n, const double* pos, const double* vel, const float* energy,
+                             const uint8_t* done, float* head, float* poi_feat, double* stats, void* stream);
+
 /* Algorithmic HBM bytes of one env-step (SURVEY.md section 8d, fp32 I/O contract):
  * 40N + 11M + 11 + 4*N*D; with_actions=0 drops 8N; with_obs=0 drops 4*N*D. */
 DCC_API int64_t dcc_env_bytes_per_step(int32_t n_agents, int32_t n_pois, int32_t with_actions, int32_t with_obs);

@@ -1,0 +1,73 @@
+/*
+ * dcc_mlp.h -- C-ABI of the fused element-wise stages of the MAPPO policy trunks in libdcc_hip.so.
+ *
+ * The reference's actor/critic trunk is  LayerNorm(in) -> [Linear -> ReLU -> LayerNorm] x 2
+ * (uav_dcc_control/algos/algo_utils/mlp.py:7-58; called by r_actor_critic.py:43-57,59-79,111-121 from
+ * Learner.collect, learner.py:227-252, and MAPPOTrainer.ppo_update, algos/mappo.py:133-187).  With 4.9 M agent rows
+ * per PPO epoch (8 UAV x 64 PoI x 4096 envs x 150 steps) every [rows, 256] activation is 5 GB, and the update is
+ * bound by the number of passes over such tensors, not by its GEMMs.  These entry points replace chains of
+ * element-wise / LayerNorm kernels by single passes:
+ *
+ *   dcc_relu_ln_fwd / _bwd      h = LayerNorm(ReLU(z))   one read + one write;  backward recomputes the
+ *                               LayerNorm statistics from z instead of storing them
+ *   dcc_actor_l1_fwd / _bwd     the actor's first block evaluated straight from the compact features of
+ *                               dcc_obs_features (include/dcc_env.h):
+ *                                   z = rstd_in * (head . Wh^T + G[env] - mean_in * s) + c ;  h = LayerNorm(ReLU(z))
+ *                               (algebra in dynamic-coverage-control_amd/algos/algo_utils/structured.py); z is never stored
+ *
+ * All pointers are DEVICE pointers to contiguous float32 (float64 for `stats`) arrays; calls are asynchronous on
+ * `stream`; return 0, or DCC_EINVAL (-1) / DCC_EHIP (-2) / DCC_EUNSUPPORTED (-4: shape outside the compiled
+ * variants -- the caller keeps its unfused path).  Parameter gradients are reduced in a fixed order (per-wave
+ * partial sums in `workspace`, then one deterministic pass), so results are reproducible run to run.
+ */
+#ifndef DCC_MLP_H
+#define DCC_MLP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef DCC_API
+#if defined(__GNUC__)
+#define DCC_API __attribute__((visibility("default")))
+#else
+#define DCC_API
+#endif
+#endif
+
+/* h[R,H] = LayerNorm_{gamma,beta,eps}(max(z, 0)) over the last axis (mlp.py:13-16 block tail: ReLU -> LayerNorm). */
+DCC_API int dcc_relu_ln_fwd(const float* z, const float* gamma, const float* beta, float eps, float* h, int64_t R,
+                            int32_t H, void* stream);
+
+/* Floats of workspace the backward calls below need for a given problem (0 if unsupported). */
+DCC_API int64_t dcc_mlp_workspace_floats(int32_t H, int32_t HD);
+
+/* Given dh = dL/dh: dz[R,H] = dL/dz, dgamma[H], dbeta[H] (written, not accumulated). */
+DCC_API int dcc_relu_ln_bwd(const float* z, const float* gamma, const float* dh, float eps, float* dz, float* dgamma,
+                            float* dbeta, float* workspace, int64_t R, int32_t H, void* stream);
+
+/*
+ * Actor first block from compact features of n env states with N agents each (rows r = e*N + i):
+ *   head  [n,N,HD] f32, HD = 4 + 2(N-1)      dcc_obs_features
+ *   G     [n,H]    f32                       per-env term  poi_feat . [We;Wd]^T + const   (shared by the N agents)
+ *   stats [n,N,2]  f64 or NULL               (mean, sum sq. dev.) of each observation row; NULL = no input LayerNorm
+ *   Wh [H,HD], s [H] (row sums of the folded weight), c [H] (folded bias);  D = observation width, eps_in = input-LN eps
+ *   gamma, beta [H], eps_ln                  the block's LayerNorm
+ *   h     [n*N,H]  f32 out
+ */
+DCC_API int dcc_actor_l1_fwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
+                             const float* c, const float* gamma, const float* beta, float eps_in, float eps_ln,
+                             int32_t D, float* h, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream);
+
+/* Backward of the above given dh [n*N,H]: dG [n,H], dWh [H,HD], ds [H], dc [H], dgamma [H], dbeta [H]. */
+DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
+                             const float* c, const float* gamma, const float* dh, float eps_in, float eps_ln, int32_t D,
+                             float* dG, float* dWh, float* ds, float* dc, float* dgamma, float* dbeta, float* workspace,
+                             int64_t n, int32_t N, int32_t HD, int32_t H, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCC_MLP_H */

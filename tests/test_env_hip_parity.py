@@ -402,3 +402,31 @@ def test_compact_state_outputs_and_obs_expansion(N, M, cfs, oracle_mod):
     assert torch.equal(env.expand_obs(o1["state_pos"], o1["state_vel"], o1["state_energy"], o1["state_done"]), o1["obs"])
     with pytest.raises(ValueError):
         env.expand_obs(o1["state_pos"].float(), o1["state_vel"], o1["state_energy"], o1["state_done"])
+
+
+@pytest.mark.parametrize("N,M", [(8, 64), (4, 20), (1, 9), (5, 37), (16, 256), (33, 700)])
+def test_obs_features_match_the_rows(N, M):
+    """dcc_obs_features(state): head columns bit-identical to the rows dcc_obs_expand writes, PoI features equal to the
+    agent-independent row columns, float64 moments equal to those of the float32 row values."""
+    import dcc_hip
+    from algos.algo_utils.structured import ObsLayout, features_from_obs
+    E, K = 13, 12
+    rs = np.random.RandomState(7 * N + M)
+    poi = rs.uniform(-1, 1, (M, 2))
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.3, 0.3, 0.95, 0.0)
+    env.reset()
+    out = env.alloc_state_out(K)
+    env.rollout(K, seed=5, out=dict(out, reward=torch.empty(K, E, device=env.device)))
+    flat = lambda t: t.reshape((K * E,) + tuple(t.shape[2:]))
+    st = [flat(out[k]) for k in ("state_pos", "state_vel", "state_energy", "state_done")]
+    rows = env.expand_obs(*st)
+    f = env.obs_features(*st)
+    ref = features_from_obs(rows, ObsLayout(N, M, poi, env.m_energy))
+    assert torch.equal(f["head"], ref["head"]) and torch.equal(f["poi_feat"], ref["poi_feat"])
+    np.testing.assert_allclose(f["stats"][..., 0].cpu().numpy(), ref["stats"][..., 0].cpu().numpy(), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(f["stats"][..., 1].cpu().numpy(), ref["stats"][..., 1].cpu().numpy(), rtol=1e-11)
+    # partial outputs
+    only = env.obs_features(*st, out=dict(stats=torch.empty(K * E, N, 2, dtype=torch.float64, device=env.device)))
+    assert torch.equal(only["stats"], f["stats"])
+    with pytest.raises(ValueError):
+        env.obs_features(st[0].float(), *st[1:])

@@ -163,6 +163,30 @@ def test_train_py_launcher_end_to_end(tmp_path):
     assert "iter: 2" in r.stdout and "value_loss" in r.stdout and "model saved" in r.stdout
 
 
+def test_graph_replay_does_not_reuse_stale_features():
+    """structured_input + use_hip_graph: the per-chunk feature cache is host state, so a graph replay (which runs no
+    Python of the rollout body) must still drop it -- the update has to see the features of the NEW rollout."""
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    lr = Learner(_cfg(n_rollout_threads=32, n_eval_rollout_threads=0, num_agents=4, num_pois=16, max_ep_len=12, n_iters=1,
+                      ppo_epoch=1, algo_hidden_size=32, save_model=False, structured_input=True, use_hip_graph=True))
+    b = lr.rl_buffer
+    for it in range(3):        # eager (+capture), then two replays
+        lr.rollout(b, lr.train_envs)
+        assert b._feat_cache == {}
+        lr.trainer.prep_training()
+        lr.trainer.train(b)        # (not rl_update: its after_update() rewrites slot 0)
+        T = b.episode_length
+        f = b.features_rows(0, T)
+        n = T * b.n_rollout_threads
+        fresh = lr.train_envs.env.obs_features(b.state_pos[:T].reshape(n, 4, 2), b.state_vel[:T].reshape(n, 4, 2),
+                                                b.state_energy[:T].reshape(n, -1), b.state_done[:T].reshape(n, -1))
+        assert torch.equal(f["head"], fresh["head"]) and torch.equal(f["stats"], fresh["stats"]), it
+    assert lr.use_hip_graph and len(lr._graphs) == 1
+    ptu.set_gpu_mode(False)
+
+
 @pytest.mark.parametrize("opt", ["use_hip_graph", "amp_bf16"])
 def test_optional_fast_paths_run(opt):
     """The two optional switches (hipGraph-captured rollout, bf16 autocast of the policy GEMMs) stay healthy."""
@@ -212,4 +236,43 @@ def test_compact_state_buffer_trains_like_the_full_buffer():
     # a second iteration keeps working (after_update + warmup on the compact slots)
     r2 = comp.rollout(comp.rl_buffer, comp.train_envs)
     assert np.isfinite(r2["reward"]) and all(np.isfinite(v) for v in comp.rl_update().values())
+    ptu.set_gpu_mode(False)
+
+
+def test_structured_input_trains_like_the_full_buffer():
+    """structured_input: actor and critic consume dcc_obs_features of the state; no observation row is ever built.
+    The rollout it collects is replayed into a full-row learner (rows regenerated with dcc_obs_expand): both must
+    compute the same values / log-probs for the stored actions and make the same PPO step up to fp32 re-association."""
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    kw = dict(n_rollout_threads=40, n_eval_rollout_threads=0, num_agents=8, num_pois=64, max_ep_len=20, n_iters=1,
+              ppo_epoch=3, algo_hidden_size=64, save_model=False, seed=9, cache_normalized_inputs=False)
+    st = Learner(_cfg(**dict(kw, structured_input=True, update_chunk_steps=8)))
+    full = Learner(_cfg(**kw))
+    torch.manual_seed(4)
+    r = st.rollout(st.rl_buffer, st.train_envs)
+    sb, fb = st.rl_buffer, full.rl_buffer
+    assert sb.structured and sb.compact and sb.obs is None and np.isfinite(r["reward"])
+    T = sb.episode_length
+    fb.obs.copy_(sb.obs_rows(0, T + 1))
+    for name in ("actions", "rewards", "masks", "value_preds", "returns", "action_log_probs", "advantages_raw"):
+        getattr(fb, name).copy_(getattr(sb, name))
+    # the stored values / log-probs came from the structured forward: the dense forward on the rows agrees
+    E, N = sb.n_rollout_threads, 8
+    with torch.no_grad():
+        full.trainer.prep_rollout()
+        v = full.policy.critic(fb.share_obs_env[3])[0]
+        logp, _ = full.policy.actor.evaluate_actions(fb.obs[3].view(E * N, -1), None, fb.actions[3].view(E * N, -1), None)
+    np.testing.assert_allclose(v.view(E).cpu().numpy(), sb.value_preds[3, :, 0, 0].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(logp.view(E, N).cpu().numpy(), sb.action_log_probs[3, :, :, 0].cpu().numpy(), rtol=1e-4, atol=1e-4)
+    i_st, i_full = st.rl_update(), full.rl_update()
+    for k in i_full:
+        np.testing.assert_allclose(i_st[k], i_full[k], rtol=5e-4, atol=1e-6, err_msg=k)
+    for (k, a), (_, b) in zip(full.policy.state_dict()["actor"].items(), st.policy.state_dict()["actor"].items()):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-3, atol=3e-5, err_msg=k)
+    for (k, a), (_, b) in zip(full.policy.state_dict()["critic"].items(), st.policy.state_dict()["critic"].items()):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-3, atol=3e-5, err_msg=k)
+    r2 = st.rollout(st.rl_buffer, st.train_envs)
+    assert np.isfinite(r2["reward"]) and all(np.isfinite(v) for v in st.rl_update().values())
     ptu.set_gpu_mode(False)

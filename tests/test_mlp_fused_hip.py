@@ -1,0 +1,136 @@
+"""-m gpu: the fused element-wise stages of the policy trunks (include/dcc_mlp.h) against the plain PyTorch fp32
+formulation of the same ops (forward values, input gradients, parameter gradients), their run-to-run determinism,
+and the shapes that must be refused."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=2e-5, atol=2e-6)
+
+
+def _close(a, b, name, rtol=2e-5, atol=2e-6):
+    scale = float(b.abs().max()) + 1e-20
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=rtol, atol=atol * max(1.0, scale), err_msg=name)
+
+
+def _close_grad(a, b, name, n_act):
+    """Two fp32 evaluations of the same pre-activation differ by ~1e-7 relative, which flips the ReLU of about one
+    activation per ten million (|z| below the rounding difference); each flip moves every gradient sum it feeds by
+    O(1).  Small cases (no flip expected) are compared tightly; for the large ones no entry may be off by more than
+    a few flips' worth."""
+    scale = float(b.abs().max()) + 1e-20
+    tol = 2e-4 if n_act < 100000 else 3e-2
+    assert float((a - b).abs().max()) <= tol * scale, (name, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("R,H", [(4099, 256), (77, 64), (5, 32), (301, 128), (130, 512), (50, 100), (1, 256), (9000, 8)])
+def test_relu_ln_matches_torch(R, H):
+    import dcc_hip
+    from algos.algo_utils import fused
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(R + H)
+    z = torch.randn(R, H, device=dev, generator=g) * 1.7 + 0.2
+    ln = torch.nn.LayerNorm(H).to(dev)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-0.5, 0.5)
+    assert dcc_hip.mlp_fused_supported(H)
+    dh = torch.randn(R, H, device=dev, generator=g)
+    z1 = z.clone().requires_grad_(True)
+    h1 = fused.relu_ln(z1, ln)
+    assert h1.grad_fn is not None and "ReluLN" in type(h1.grad_fn).__name__      # the HIP path ran, not the fallback
+    h1.backward(dh)
+    g1 = (z1.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone())
+    ln.zero_grad()
+    z2 = z.clone().requires_grad_(True)
+    h2 = ln(torch.relu(z2))
+    h2.backward(dh)
+    _close(h1.detach(), h2.detach(), "h")
+    _close(g1[0], z2.grad, "dz")
+    _close(g1[1], ln.weight.grad, "dgamma", rtol=1e-4, atol=1e-5)
+    _close(g1[2], ln.bias.grad, "dbeta", rtol=1e-4, atol=1e-5)
+    # deterministic: same bits on a second run
+    ln.zero_grad()
+    z3 = z.clone().requires_grad_(True)
+    fused.relu_ln(z3, ln).backward(dh)
+    assert torch.equal(z3.grad, g1[0]) and torch.equal(ln.weight.grad, g1[1]) and torch.equal(ln.bias.grad, g1[2])
+
+
+def test_unsupported_width_falls_back_to_torch_ops():
+    import dcc_hip
+    from algos.algo_utils import fused
+    dev = torch.device("cuda", 0)
+    assert not dcc_hip.mlp_fused_supported(1000) and not dcc_hip.mlp_fused_supported(130)
+    ln = torch.nn.LayerNorm(130).to(dev)
+    z = torch.randn(7, 130, device=dev, requires_grad=True)
+    h = fused.relu_ln(z, ln)
+    assert "ReluLN" not in type(h.grad_fn).__name__
+    assert torch.equal(h, ln(torch.relu(z)))
+
+
+@pytest.mark.parametrize("feature_norm", [True, False])
+@pytest.mark.parametrize("N,M,H,n", [(8, 64, 256, 517), (4, 20, 64, 33), (1, 9, 32, 5), (5, 37, 128, 70), (16, 256, 256, 40),
+                                     (11, 30, 256, 19)])
+def test_actor_first_block_matches_torch(N, M, H, n, feature_norm):
+    """fused actor L1 (from dcc_obs_features of random states) == the torch formulation of structured.actor_trunk's
+    first block == LayerNorm(ReLU(Linear(LayerNorm(rows)))) on the rows dcc_obs_expand builds."""
+    import dcc_hip
+    from argparse import Namespace
+    from algos.algo_utils import fused, structured as S
+    from algos.algo_utils.mlp import MLPBase
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(N * 100 + M)
+    poi = rs.uniform(-1, 1, (M, 2))
+    env = dcc_hip.HipCoverageEnv(n, N, M, poi, 0.3, 0.3, 0.95, 0.0)
+    env.reset()
+    K = 6
+    st = env.alloc_state_out(K)
+    env.rollout(K, seed=3, out=dict(st, reward=torch.empty(K, n, device=dev)))
+    state = [st[k][-1].contiguous() for k in ("state_pos", "state_vel", "state_energy", "state_done")]
+    feats = env.obs_features(*state)
+    rows = env.expand_obs(*state)
+    lay = S.ObsLayout(N, M, poi, env.m_energy)
+    torch.manual_seed(1)
+    cfg = Namespace(use_feature_normalization=feature_norm, algo_hidden_size=H, layer_N=1, use_orthogonal=True, use_ReLU=True)
+    base = MLPBase(cfg, (lay.D,)).to(dev)
+    with torch.no_grad():
+        if feature_norm:
+            base.feature_norm.weight.uniform_(0.5, 1.5); base.feature_norm.bias.uniform_(-0.3, 0.3)
+        base.mlp.fc1[2].weight.uniform_(0.5, 1.5); base.mlp.fc1[2].bias.uniform_(-0.3, 0.3)
+    assert dcc_hip.mlp_fused_supported(H, lay.HD)
+    dh = torch.randn(n * N, H, device=dev)
+    params = list(base.parameters())
+
+    def run(enabled, dense=False):
+        fused.ENABLED = enabled
+        try:
+            for p in params:
+                p.grad = None
+            out = base(rows.view(n * N, lay.D)) if dense else S.actor_trunk(base, lay, feats)
+            out.backward(dh)
+            return out.detach().clone(), [None if p.grad is None else p.grad.clone() for p in params]
+        finally:
+            fused.ENABLED = True
+
+    o_f, g_f = run(True)
+    o_t, g_t = run(False)
+    o_d, g_d = run(False, dense=True)
+    _close(o_f, o_t, "fused vs torch-structured", rtol=1e-4, atol=1e-5)
+    _close(o_f, o_d, "fused vs dense rows", rtol=2e-4, atol=2e-5)
+    for (name, _), a, b, d in zip(base.named_parameters(), g_f, g_t, g_d):
+        _close_grad(a, b, "grad " + name, n * N * H)
+        _close_grad(a, d, "grad(dense) " + name, n * N * H)
+    o_f2, g_f2 = run(True)
+    assert torch.equal(o_f, o_f2) and all(torch.equal(a, b) for a, b in zip(g_f, g_f2))
+
+
+def test_shapes_outside_the_compiled_variants_are_refused():
+    import dcc_hip
+    L = dcc_hip.load_library()
+    assert L.dcc_mlp_workspace_floats(256, 18) > 0 and L.dcc_mlp_workspace_floats(256, 0) > 0
+    assert L.dcc_mlp_workspace_floats(1000, 0) == 0 and L.dcc_mlp_workspace_floats(256, 41) == 0
+    z = torch.zeros(4, 1000, device="cuda")
+    v = torch.zeros(1000, device="cuda")
+    rc = L.dcc_relu_ln_fwd(z.data_ptr(), v.data_ptr(), v.data_ptr(), 1e-5, z.data_ptr(), 4, 1000, None)
+    assert rc == -4
