@@ -14,15 +14,16 @@ class ACTLayer(nn.Module):
         self.continuous_action = True
         self.action_out = DiagGaussian(inputs_dim, action_space.shape[0], use_orthogonal, gain)
 
-    def forward(self, x, available_actions=None, deterministic=False):
-        dist = self.action_out(x)
+    def forward(self, x, available_actions=None, deterministic=False, mean=None):
+        """mean: the Gaussian mean fc_mean(x) when the caller already has it (fused with the trunk), else from x."""
+        dist = self.action_out(x, mean=mean)
         actions = dist.mode() if deterministic else dist.sample()
         return actions, dist.log_probs(actions)
 
-    def evaluate_actions(self, x, action, available_actions=None, active_masks=None):
+    def evaluate_actions(self, x, action, available_actions=None, active_masks=None, mean=None):
         """log pi(a|s) summed over action dims [B,1]; entropy summed over dims and averaged over the
         (active) batch -- act.py:173-179 multiplies the per-dim entropy [B,A] by the mask [B,1]."""
-        dist = self.action_out(x)
+        dist = self.action_out(x, mean=mean)
         logp = dist.log_probs(action)
         ent = dist.entropy()
         if active_masks is not None:

@@ -42,8 +42,9 @@ class DiagGaussian(nn.Module):
         self.fc_mean = init(nn.Linear(num_inputs, num_outputs), init_method, lambda b: nn.init.constant_(b, 0), gain)
         self.logstd = AddBias(torch.zeros(num_outputs))
 
-    def forward(self, x):
-        mean = self.fc_mean(x)
+    def forward(self, x, mean=None):
+        if mean is None:
+            mean = self.fc_mean(x)
         logstd = self.logstd(torch.zeros_like(mean))
         # validate_args=False: the default argument validation does `(scale > 0).all()` on the host -- a device
         # synchronisation per call (and illegal inside a hipGraph capture); exp() is positive by construction

@@ -31,14 +31,17 @@ class MLPLayer(nn.Module):
     def run_block(blk, x):
         """Linear -> act -> LayerNorm; the ReLU + LayerNorm tail is one fused HIP pass on the GPU (dcc_mlp.h)."""
         if isinstance(blk[1], nn.ReLU):
-            return fused.relu_ln(blk[0](x), blk[2])
+            return fused.relu_ln(fused.linear_nobias(x, blk[0]), blk[0].bias, blk[2])
         return blk(x)
 
-    def forward(self, x):
-        x = self.run_block(self.fc1, x)
-        for blk in self.fc2:
+    def forward(self, x, head=None):
+        """head: optional narrow nn.Linear applied to the features; fused with the last block's tail on the GPU."""
+        blocks = [self.fc1] + list(self.fc2)
+        for i, blk in enumerate(blocks):
+            if head is not None and i == len(blocks) - 1 and isinstance(blk[1], nn.ReLU):
+                return fused.relu_ln_head(fused.linear_nobias(x, blk[0]), blk[0].bias, blk[2], head)
             x = self.run_block(blk, x)
-        return x
+        return x if head is None else head(x)
 
 
 class MLPBase(nn.Module):
@@ -51,10 +54,10 @@ class MLPBase(nn.Module):
             self.feature_norm = nn.LayerNorm(obs_dim)
         self.mlp = MLPLayer(obs_dim, self.hidden_size, cfg.layer_N, cfg.use_orthogonal, cfg.use_ReLU)
 
-    def forward(self, x):
+    def forward(self, x, head=None):
         if self._use_feature_normalization:
             x = self.feature_norm(x)
-        return self.mlp(x)
+        return self.mlp(x, head)
 
     # ---- input-normalisation cache for the PPO epochs ---------------------------------------------------
     # LayerNorm(x) = xhat * gamma + beta with xhat = (x - mean) / sqrt(var + eps) independent of the
@@ -70,16 +73,25 @@ class MLPBase(nn.Module):
         ln = self.feature_norm
         return F.layer_norm(x, ln.normalized_shape, None, None, ln.eps)
 
-    def forward_prenormalized(self, xhat):
+    def forward_prenormalized(self, xhat, head=None):
         lin = self.mlp.fc1[0]
         if self._use_feature_normalization:
             ln = self.feature_norm
             w = lin.weight * ln.weight.unsqueeze(0)
             b = lin.bias + lin.weight @ ln.bias
-            h = F.linear(xhat, w, b)
         else:
-            h = lin(xhat)
-        h = fused.relu_ln(h, self.mlp.fc1[2]) if isinstance(self.mlp.fc1[1], nn.ReLU) else self.mlp.fc1[2](self.mlp.fc1[1](h))
-        for blk in self.mlp.fc2:
+            w, b = lin.weight, lin.bias
+        relu1 = isinstance(self.mlp.fc1[1], nn.ReLU)
+        blocks = list(self.mlp.fc2)
+        if relu1:
+            z = fused.linear_w(xhat, w)
+            if head is not None and not blocks:
+                return fused.relu_ln_head(z, b, self.mlp.fc1[2], head)
+            h = fused.relu_ln(z, b, self.mlp.fc1[2])
+        else:
+            h = self.mlp.fc1[2](self.mlp.fc1[1](F.linear(xhat, w, b)))
+        for i, blk in enumerate(blocks):
+            if head is not None and i == len(blocks) - 1 and isinstance(blk[1], nn.ReLU):
+                return fused.relu_ln_head(fused.linear_nobias(h, blk[0]), blk[0].bias, blk[2], head)
             h = self.mlp.run_block(blk, h)
-        return h
+        return h if head is None else head(h)

@@ -80,52 +80,59 @@ def _split(wf, layout):
     return wf[..., :HD], poi[..., 0:2], poi[..., 2], poi[..., 3], poi[..., 4]
 
 
-def _tail(blk, z):
-    """activation + LayerNorm of a `Linear -> act -> LayerNorm` block on its pre-activation z (fused when ReLU)."""
+def _tail(blk, z, bias=None):
+    """activation + LayerNorm of a `Linear -> act -> LayerNorm` block on its pre-activation z + bias (fused when ReLU)."""
     if isinstance(blk[1], nn.ReLU):
-        return fused.relu_ln(z, blk[2])
-    return blk[2](blk[1](z))
+        return fused.relu_ln(z, bias, blk[2])
+    return blk[2](blk[1](z if bias is None else z + bias))
 
 
-def _rest(base, h):
-    for blk in base.mlp.fc2:
-        h = _tail(blk, blk[0](h))
-    return h
+def _rest(base, h, head=None):
+    """fc2 blocks on the first block's output; with `head` (a narrow nn.Linear) returns head(features), the last
+    block's ReLU + LayerNorm and the head in one pass."""
+    blocks = list(base.mlp.fc2)
+    for i, blk in enumerate(blocks):
+        z = fused.linear_nobias(h, blk[0])
+        if head is not None and i == len(blocks) - 1 and isinstance(blk[1], nn.ReLU):
+            return fused.relu_ln_head(z, blk[0].bias, blk[2], head)
+        h = _tail(blk, z, blk[0].bias)
+    return h if head is None else head(h)
 
 
-def actor_trunk(base, layout, feats):
-    """MLPBase(obs rows) for the n*N agent rows described by feats -> [n*N, H]."""
-    head, poi_feat, stats = feats["head"], feats["poi_feat"], feats["stats"]
-    n, N, HD = head.shape
+def actor_trunk(base, layout, feats, head=None):
+    """MLPBase(obs rows) for the n*N agent rows described by feats -> [n*N, H] (or head(.) -> [n*N, A])."""
+    head_f, poi_feat, stats = feats["head"], feats["poi_feat"], feats["stats"]
+    n, N, HD = head_f.shape
     wf, c, eps = _folded(base)                                   # [H, D], [H]
     w_head, w_xy, w_e, w_m, w_d = _split(wf, layout)
     w_h = torch.cat([w_head[:, :2], w_head[:, 2:4] - w_xy.sum(1), w_head[:, 4:]], dim=1)       # pos_i also shifts every PoI
     const = (w_xy * layout.poi(wf)).sum((1, 2)) + layout.m_energy * w_m.sum(1)        # [H]
-    g = F.linear(poi_feat, torch.cat([w_e, w_d], dim=1), const).to(wf.dtype)                   # [n, H] shared by the agents
+    g = (fused.linear_w(poi_feat, torch.cat([w_e, w_d], dim=1)) + const).to(wf.dtype)          # [n, H] shared by the agents
     blk = base.mlp.fc1
     if isinstance(blk[1], nn.ReLU):   # one fused pass: the pre-activation never reaches memory (include/dcc_mlp.h)
-        h = fused.actor_l1(head, g, stats if eps is not None else None, w_h, wf.sum(1), c, blk[2], eps, layout.D)
-        return _rest(base, h)
-    z = F.linear(head.reshape(n * N, HD), w_h).view(n, N, -1) + g.unsqueeze(1)
+        h = fused.actor_l1(head_f, g, stats if eps is not None else None, w_h, wf.sum(1), c, blk[2], eps, layout.D)
+        return _rest(base, h, head)
+    z = F.linear(head_f.reshape(n * N, HD), w_h).view(n, N, -1) + g.unsqueeze(1)
     if eps is not None:
         mean = stats[..., 0]
         rstd = torch.rsqrt(stats[..., 1] / layout.D + eps)
         z = rstd.to(wf.dtype).unsqueeze(-1) * (z - mean.to(wf.dtype).unsqueeze(-1) * wf.sum(1)) + c
     else:
         z = z + c
-    return _rest(base, _tail(blk, z.reshape(n * N, -1)))
+    return _rest(base, _tail(blk, z.reshape(n * N, -1)), head)
 
 
-def critic_trunk(base, layout, feats):
-    """MLPBase(centralised rows = concat of the N agent rows of an env) -> [n, H]."""
-    head, poi_feat, stats = feats["head"], feats["poi_feat"], feats["stats"]
-    n, N, HD = head.shape
+def critic_trunk(base, layout, feats, head=None):
+    """MLPBase(centralised rows = concat of the N agent rows of an env) -> [n, H] (or head(.) -> [n, A])."""
+    head_f, poi_feat, stats = feats["head"], feats["poi_feat"], feats["stats"]
+    n, N, HD = head_f.shape
     wf, c, eps = _folded(base)                                   # [H, N*D]
     H = wf.shape[0]
     w_head, w_xy, w_e, w_m, w_d = _split(wf.view(H, N, layout.D), layout)      # per-agent blocks
     w_h = torch.cat([w_head[..., :2], w_head[..., 2:4] - w_xy.sum(2), w_head[..., 4:]], dim=-1).reshape(H, N * HD)
     const = (w_xy * layout.poi(wf)).sum((1, 2, 3)) + layout.m_energy * w_m.sum((1, 2))
-    z = F.linear(head.reshape(n, N * HD), w_h) + F.linear(poi_feat, torch.cat([w_e.sum(1), w_d.sum(1)], dim=1), const).to(wf.dtype)
+    z = (fused.linear_w(head_f.reshape(n, N * HD), w_h)
+         + (fused.linear_w(poi_feat, torch.cat([w_e.sum(1), w_d.sum(1)], dim=1)) + const).to(wf.dtype))
     if eps is not None:
         mean_i, m2_i = stats[..., 0], stats[..., 1]                            # [n, N] float64
         mean = mean_i.mean(1, keepdim=True)
@@ -134,4 +141,4 @@ def critic_trunk(base, layout, feats):
         z = rstd.to(wf.dtype) * (z - mean.to(wf.dtype) * wf.sum(1)) + c
     else:
         z = z + c
-    return _rest(base, _tail(base.mlp.fc1, z))
+    return _rest(base, _tail(base.mlp.fc1, z), head)

@@ -38,18 +38,19 @@ class R_Actor(nn.Module):
         self.obs_layout = None    # set by MAPPOPolicy.enable_structured_input
         self.to(device)
 
-    def _trunk(self, obs, prenormalized=False):
-        """obs: rows [B, D], or the dict of compact features of B/N env states (algo_utils/structured.py)."""
+    def _mean(self, obs, prenormalized=False):
+        """Gaussian mean [B, A] = fc_mean(trunk(obs)) (the head is fused with the trunk's last block on the GPU).
+        obs: rows [B, D], or the dict of compact features of B/N env states (algo_utils/structured.py)."""
+        head = self.act.action_out.fc_mean
         if isinstance(obs, dict):
             if self.obs_layout is None:
                 raise RuntimeError("compact features passed to an actor without an observation layout")
-            return structured.actor_trunk(self.base, self.obs_layout, obs)
+            return structured.actor_trunk(self.base, self.obs_layout, obs, head)
         obs = check(obs).to(**self.tpdv)
-        return self.base.forward_prenormalized(obs) if prenormalized else self.base(obs)
+        return self.base.forward_prenormalized(obs, head) if prenormalized else self.base(obs, head)
 
     def forward(self, obs, rnn_states=None, masks=None, available_actions=None, deterministic=False):
-        feats = self._trunk(obs)
-        actions, logp = self.act(feats, available_actions, deterministic)
+        actions, logp = self.act(None, available_actions, deterministic, mean=self._mean(obs))
         return actions, logp, rnn_states
 
     def evaluate_actions(self, obs, rnn_states, action, masks, available_actions=None, active_masks=None,
@@ -58,9 +59,9 @@ class R_Actor(nn.Module):
         action = check(action).to(**self.tpdv)
         if active_masks is not None:
             active_masks = check(active_masks).to(**self.tpdv)
-        feats = self._trunk(obs, prenormalized)
-        return self.act.evaluate_actions(feats, action, available_actions,
-                                         active_masks=active_masks if self._use_policy_active_masks else None)
+        return self.act.evaluate_actions(None, action, available_actions,
+                                         active_masks=active_masks if self._use_policy_active_masks else None,
+                                         mean=self._mean(obs, prenormalized))
 
 
 class R_Critic(nn.Module):
@@ -83,8 +84,7 @@ class R_Critic(nn.Module):
         if isinstance(cent_obs, dict):
             if self.obs_layout is None:
                 raise RuntimeError("compact features passed to a critic without an observation layout")
-            feats = structured.critic_trunk(self.base, self.obs_layout, cent_obs)
-        else:
-            cent_obs = check(cent_obs).to(**self.tpdv)
-            feats = self.base.forward_prenormalized(cent_obs) if prenormalized else self.base(cent_obs)
-        return self.v_out(feats), rnn_states
+            return structured.critic_trunk(self.base, self.obs_layout, cent_obs, self.v_out), rnn_states
+        cent_obs = check(cent_obs).to(**self.tpdv)
+        v = self.base.forward_prenormalized(cent_obs, self.v_out) if prenormalized else self.base(cent_obs, self.v_out)
+        return v, rnn_states

@@ -65,13 +65,14 @@ __device__ __forceinline__ void row_stats(const float (&a)[VPL][VEC], const bool
 
 // ---- h = LayerNorm(ReLU(z)) -------------------------------------------------------------------------------------
 template <int VEC, int VPL>
-__global__ __launch_bounds__(kBlock) void relu_ln_fwd_k(const float* __restrict__ z, const float* __restrict__ gamma,
+__global__ __launch_bounds__(kBlock) void relu_ln_fwd_k(const float* __restrict__ z, const float* __restrict__ bias,
+                                                        const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         float* __restrict__ h, long long R, int H) {
     const int lane = threadIdx.x & 63;
     const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const long long nw = (long long)gridDim.x * kWavesPerBlock;
-    float g[VPL][VEC], b[VPL][VEC];
+    float g[VPL][VEC], b[VPL][VEC], zb[VPL][VEC];
     bool ok[VPL];
     int cb[VPL];
 #pragma unroll
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(kBlock) void relu_ln_fwd_k(const float* __restrict_
         cb[v] = (v * 64 + lane) * VEC;
         ok[v] = cb[v] < H;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { g[v][j] = 0.f; b[v][j] = 0.f; }
-        if (ok[v]) { ld<VEC>(gamma + cb[v], g[v]); ld<VEC>(beta + cb[v], b[v]); }
+        for (int j = 0; j < VEC; ++j) { g[v][j] = 0.f; b[v][j] = 0.f; zb[v][j] = 0.f; }
+        if (ok[v]) { ld<VEC>(gamma + cb[v], g[v]); ld<VEC>(beta + cb[v], b[v]); if (bias) ld<VEC>(bias + cb[v], zb[v]); }
     }
     const float invH = 1.0f / (float)H;
     for (long long r = gw; r < R; r += nw) {
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void relu_ln_fwd_k(const float* __restrict_
             if (ok[v]) {
                 ld<VEC>(z + r * H + cb[v], a[v]);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) a[v][j] = fmaxf(a[v][j], 0.f);
+                for (int j = 0; j < VEC; ++j) a[v][j] = fmaxf(a[v][j] + zb[v][j], 0.f);
             }
         }
         float mean, rstd;
@@ -137,14 +138,15 @@ __device__ __forceinline__ void row_bwd(const float (&zr)[VPL][VEC], const float
 }
 
 template <int VEC, int VPL>
-__global__ __launch_bounds__(kBlock) void relu_ln_bwd_k(const float* __restrict__ z, const float* __restrict__ gamma,
+__global__ __launch_bounds__(kBlock) void relu_ln_bwd_k(const float* __restrict__ z, const float* __restrict__ bias,
+                                                        const float* __restrict__ gamma,
                                                         const float* __restrict__ dh, float eps,
                                                         float* __restrict__ dz, float* __restrict__ ws, long long R,
                                                         int H) {
     const int lane = threadIdx.x & 63;
     const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const long long nw = (long long)gridDim.x * kWavesPerBlock;
-    float g[VPL][VEC], acc_g[VPL][VEC], acc_b[VPL][VEC];
+    float g[VPL][VEC], zb[VPL][VEC], acc_g[VPL][VEC], acc_b[VPL][VEC], acc_z[VPL][VEC];
     bool ok[VPL];
     int cb[VPL];
 #pragma unroll
@@ -152,8 +154,8 @@ __global__ __launch_bounds__(kBlock) void relu_ln_bwd_k(const float* __restrict_
         cb[v] = (v * 64 + lane) * VEC;
         ok[v] = cb[v] < H;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { g[v][j] = 0.f; acc_g[v][j] = 0.f; acc_b[v][j] = 0.f; }
-        if (ok[v]) ld<VEC>(gamma + cb[v], g[v]);
+        for (int j = 0; j < VEC; ++j) { g[v][j] = 0.f; zb[v][j] = 0.f; acc_g[v][j] = 0.f; acc_b[v][j] = 0.f; acc_z[v][j] = 0.f; }
+        if (ok[v]) { ld<VEC>(gamma + cb[v], g[v]); if (bias) ld<VEC>(bias + cb[v], zb[v]); }
     }
     const float invH = 1.0f / (float)H;
     for (long long r = gw; r < R; r += nw) {
@@ -162,7 +164,11 @@ __global__ __launch_bounds__(kBlock) void relu_ln_bwd_k(const float* __restrict_
         for (int v = 0; v < VPL; ++v) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { zr[v][j] = 0.f; d[v][j] = 0.f; }
-            if (ok[v]) { ld<VEC>(z + r * H + cb[v], zr[v]); ld<VEC>(dh + r * H + cb[v], d[v]); }
+            if (ok[v]) {
+                ld<VEC>(z + r * H + cb[v], zr[v]); ld<VEC>(dh + r * H + cb[v], d[v]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) zr[v][j] += zb[v][j];
+            }
 #pragma unroll
             for (int j = 0; j < VEC; ++j) a[v][j] = fmaxf(zr[v][j], 0.f);
         }
@@ -170,26 +176,177 @@ __global__ __launch_bounds__(kBlock) void relu_ln_bwd_k(const float* __restrict_
         row_stats<VEC, VPL>(a, ok, invH, eps, mean, rstd);
         row_bwd<VEC, VPL>(zr, a, d, g, ok, invH, mean, rstd, acc_g, acc_b);
 #pragma unroll
-        for (int v = 0; v < VPL; ++v)
+        for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc_z[v][j] += d[v][j];
             if (ok[v]) st<VEC>(dz + r * H + cb[v], d[v]);
+        }
     }
-    float* w = ws + gw * 2 * H;   // per-wave partials: [dgamma | dbeta]
+    float* w = ws + gw * 3 * H;   // per-wave partials: [dgamma | dbeta | dbias]
 #pragma unroll
     for (int v = 0; v < VPL; ++v)
-        if (ok[v]) { st<VEC>(w + cb[v], acc_g[v]); st<VEC>(w + H + cb[v], acc_b[v]); }
+        if (ok[v]) { st<VEC>(w + cb[v], acc_g[v]); st<VEC>(w + H + cb[v], acc_b[v]); st<VEC>(w + 2 * H + cb[v], acc_z[v]); }
+}
+
+// ---- y = Linear_{Wo,bo}(LayerNorm(ReLU(z))) with a narrow output (A <= 4 columns: action mean / value) -------------
+// The normalised activations h never reach memory: the forward writes only y [R,A]; the backward recomputes h from z,
+// forms dh = dy Wo on the fly and accumulates dWo += dy^T h next to dgamma / dbeta.
+constexpr int kAMax = 4;
+
+template <int VEC, int VPL>
+__global__ __launch_bounds__(kBlock) void relu_ln_head_fwd_k(const float* __restrict__ z, const float* __restrict__ zbias,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             const float* __restrict__ Wo, const float* __restrict__ bo,
+                                                             float* __restrict__ y, long long R, int H, int A) {
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * kWavesPerBlock;
+    float g[VPL][VEC], b[VPL][VEC], zb[VPL][VEC], wo[kAMax][VPL][VEC];
+    bool ok[VPL];
+    int cb[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        cb[v] = (v * 64 + lane) * VEC;
+        ok[v] = cb[v] < H;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { g[v][j] = 0.f; b[v][j] = 0.f; zb[v][j] = 0.f; }
+        if (ok[v]) { ld<VEC>(gamma + cb[v], g[v]); ld<VEC>(beta + cb[v], b[v]); if (zbias) ld<VEC>(zbias + cb[v], zb[v]); }
+#pragma unroll
+        for (int o = 0; o < kAMax; ++o) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) wo[o][v][j] = 0.f;
+            if (ok[v] && o < A) ld<VEC>(Wo + o * H + cb[v], wo[o][v]);
+        }
+    }
+    float bias = 0.f;
+    if (lane < A) bias = bo ? bo[lane] : 0.f;
+    const float invH = 1.0f / (float)H;
+    for (long long r = gw; r < R; r += nw) {
+        float a[VPL][VEC];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a[v][j] = 0.f;
+            if (ok[v]) {
+                ld<VEC>(z + r * H + cb[v], a[v]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) a[v][j] = fmaxf(a[v][j] + zb[v][j], 0.f);
+            }
+        }
+        float mean, rstd;
+        row_stats<VEC, VPL>(a, ok, invH, eps, mean, rstd);
+        float part[kAMax] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+            if (ok[v]) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float hh = (a[v][j] - mean) * rstd * g[v][j] + b[v][j];
+#pragma unroll
+                    for (int o = 0; o < kAMax; ++o) part[o] += hh * wo[o][v][j];
+                }
+            }
+        float out = 0.f;
+#pragma unroll
+        for (int o = 0; o < kAMax; ++o)
+            if (o < A) {
+                const float t = wave_sum(part[o]);
+                if (lane == o) out = t + bias;
+            }
+        if (lane < A) y[r * A + lane] = out;
+    }
+}
+
+template <int VEC, int VPL>
+__global__ __launch_bounds__(kBlock) void relu_ln_head_bwd_k(const float* __restrict__ z, const float* __restrict__ zbias,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             const float* __restrict__ Wo, const float* __restrict__ dy,
+                                                             float* __restrict__ dz, float* __restrict__ ws, long long R,
+                                                             int H, int A) {
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * kWavesPerBlock;
+    float g[VPL][VEC], b[VPL][VEC], zb[VPL][VEC], wo[kAMax][VPL][VEC];
+    float acc_g[VPL][VEC], acc_b[VPL][VEC], acc_z[VPL][VEC], acc_w[kAMax][VPL][VEC];
+    bool ok[VPL];
+    int cb[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        cb[v] = (v * 64 + lane) * VEC;
+        ok[v] = cb[v] < H;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { g[v][j] = 0.f; b[v][j] = 0.f; zb[v][j] = 0.f; acc_g[v][j] = 0.f; acc_b[v][j] = 0.f; acc_z[v][j] = 0.f; }
+        if (ok[v]) { ld<VEC>(gamma + cb[v], g[v]); ld<VEC>(beta + cb[v], b[v]); if (zbias) ld<VEC>(zbias + cb[v], zb[v]); }
+#pragma unroll
+        for (int o = 0; o < kAMax; ++o) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { wo[o][v][j] = 0.f; acc_w[o][v][j] = 0.f; }
+            if (ok[v] && o < A) ld<VEC>(Wo + o * H + cb[v], wo[o][v]);
+        }
+    }
+    const float invH = 1.0f / (float)H;
+    for (long long r = gw; r < R; r += nw) {
+        float zr[VPL][VEC], a[VPL][VEC], d[VPL][VEC];
+        float dyr[kAMax];
+#pragma unroll
+        for (int o = 0; o < kAMax; ++o) dyr[o] = o < A ? dy[r * A + o] : 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) zr[v][j] = 0.f;
+            if (ok[v]) {
+                ld<VEC>(z + r * H + cb[v], zr[v]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) zr[v][j] += zb[v][j];
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a[v][j] = fmaxf(zr[v][j], 0.f);
+        }
+        float mean, rstd;
+        row_stats<VEC, VPL>(a, ok, invH, eps, mean, rstd);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float hh = ok[v] ? (a[v][j] - mean) * rstd * g[v][j] + b[v][j] : 0.f;
+                float t = 0.f;
+#pragma unroll
+                for (int o = 0; o < kAMax; ++o) { t += dyr[o] * wo[o][v][j]; acc_w[o][v][j] += dyr[o] * hh; }
+                d[v][j] = t;
+            }
+        row_bwd<VEC, VPL>(zr, a, d, g, ok, invH, mean, rstd, acc_g, acc_b);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc_z[v][j] += d[v][j];
+            if (ok[v]) st<VEC>(dz + r * H + cb[v], d[v]);
+        }
+    }
+    float* w = ws + gw * (3 + kAMax) * H;   // per-wave partials: [dgamma | dbeta | dbias | dWo rows]
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+        if (ok[v]) {
+            st<VEC>(w + cb[v], acc_g[v]);
+            st<VEC>(w + H + cb[v], acc_b[v]);
+            st<VEC>(w + 2 * H + cb[v], acc_z[v]);
+#pragma unroll
+            for (int o = 0; o < kAMax; ++o) st<VEC>(w + (3 + o) * H + cb[v], acc_w[o][v]);
+        }
 }
 
 // out[p] = sum over the nw per-wave partial vectors (fixed order).
-__global__ __launch_bounds__(kBlock) void reduce_partials_k(const float* __restrict__ ws, long long nw, int P,
+__global__ __launch_bounds__(kBlock) void reduce_partials_k(const float* __restrict__ ws, long long nw, int P, int stride,
                                                             float* __restrict__ out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     long long w = 0;
     for (; w + 3 < nw; w += 4) {
-        s0 += ws[w * P + p]; s1 += ws[(w + 1) * P + p]; s2 += ws[(w + 2) * P + p]; s3 += ws[(w + 3) * P + p];
+        s0 += ws[w * stride + p]; s1 += ws[(w + 1) * stride + p]; s2 += ws[(w + 2) * stride + p]; s3 += ws[(w + 3) * stride + p];
     }
-    for (; w < nw; ++w) s0 += ws[w * P + p];
+    for (; w < nw; ++w) s0 += ws[w * stride + p];
     out[p] = (s0 + s1) + (s2 + s3);
 }
 
@@ -331,6 +488,21 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc_w[k][v][j] = 0.f;
     const float invH = 1.0f / (float)H;
+    // software pipeline: the loads of the next row (dh, head, input moments) are issued before the current row is
+    // processed -- with ~100 accumulator registers per lane only two waves fit a SIMD, too few to hide HBM latency
+    float nd[VPL][VEC], nhv = 0.f;
+    double nm = 0.0, nm2 = 0.0;
+    auto fetch = [&](long long r) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) nd[v][j] = 0.f;
+            if (ok[v]) ld<VEC>(dh + r * H + cb[v], nd[v]);
+        }
+        nhv = lane < HD ? head[r * HD + lane] : 0.f;
+        if (stats) { nm = stats[2 * r]; nm2 = stats[2 * r + 1]; }
+    };
+    if (gw < n) fetch(gw * N);
     for (long long e = gw; e < n; e += nw) {
         float Gv[VPL][VEC], dGv[VPL][VEC];
 #pragma unroll
@@ -341,16 +513,17 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
         }
         for (int i = 0; i < N; ++i) {
             const long long r = e * N + i;
-            const float hv = lane < HD ? head[r * HD + lane] : 0.f;
-            float mean_in, rstd_in;
-            in_stats(stats, r, D, eps_in, mean_in, rstd_in);
-            float zr[VPL][VEC], a[VPL][VEC], d[VPL][VEC];
+            float d[VPL][VEC];
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) {
+            for (int v = 0; v < VPL; ++v)
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) d[v][j] = 0.f;
-                if (ok[v]) ld<VEC>(dh + r * H + cb[v], d[v]);
-            }
+                for (int j = 0; j < VEC; ++j) d[v][j] = nd[v][j];
+            const float hv = nhv;
+            float mean_in = 0.f, rstd_in = 1.f;
+            if (stats) { mean_in = (float)nm; rstd_in = (float)(1.0 / sqrt(nm2 / (double)D + (double)eps_in)); }
+            const long long rn = (i + 1 < N) ? r + 1 : ((e + nw < n) ? (e + nw) * N : -1);
+            if (rn >= 0) fetch(rn);
+            float zr[VPL][VEC], a[VPL][VEC];
             l1_row_z<VEC, VPL>(Wt, H, HD, hv, mean_in, rstd_in, Gv, sv, cv, cb, ok, zr);
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
@@ -473,13 +646,13 @@ DCC_API int64_t dcc_mlp_workspace_floats(int32_t H, int32_t HD) {
     if (!pick_shape(H, sh)) return 0;
     const int hdp = pad_hd(HD);
     if (hdp < 0) return 0;
-    const int64_t a = (int64_t)kReluLnBlocks * kWavesPerBlock * 2 * H;
+    const int64_t a = (int64_t)kReluLnBlocks * kWavesPerBlock * (3 + kAMax) * H;
     const int64_t b = HD > 0 ? (int64_t)kL1Blocks * kWavesPerBlock * (hdp + 4) * H : 0;
     return a > b ? a : b;
 }
 
-DCC_API int dcc_relu_ln_fwd(const float* z, const float* gamma, const float* beta, float eps, float* h, int64_t R,
-                            int32_t H, void* stream) {
+DCC_API int dcc_relu_ln_fwd(const float* z, const float* bias, const float* gamma, const float* beta, float eps, float* h,
+                            int64_t R, int32_t H, void* stream) {
     if (!z || !gamma || !beta || !h || R < 0) return kEINVAL;
     Shape sh;
     if (!pick_shape(H, sh)) return kEUNSUPPORTED;
@@ -487,24 +660,56 @@ DCC_API int dcc_relu_ln_fwd(const float* z, const float* gamma, const float* bet
     if (R == 0) return 0;
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
     const int grid = (int)waves_for(R, kReluLnBlocks);
-    LAUNCH_SHAPE(relu_ln_fwd_k, grid, 0, z, gamma, beta, eps, h, (long long)R, (int)H);
+    LAUNCH_SHAPE(relu_ln_fwd_k, grid, 0, z, bias, gamma, beta, eps, h, (long long)R, (int)H);
     return hipGetLastError() == hipSuccess ? 0 : kEHIP;
 }
 
-DCC_API int dcc_relu_ln_bwd(const float* z, const float* gamma, const float* dh, float eps, float* dz, float* dgamma,
-                            float* dbeta, float* workspace, int64_t R, int32_t H, void* stream) {
-    if (!z || !gamma || !dh || !dz || !dgamma || !dbeta || !workspace || R < 1) return kEINVAL;
-    if (dbeta != dgamma + H) return kEINVAL;   // [dgamma | dbeta] must be one contiguous [2,H] array
+DCC_API int dcc_relu_ln_bwd(const float* z, const float* bias, const float* gamma, const float* dh, float eps, float* dz,
+                            float* dparams, float* workspace, int64_t R, int32_t H, void* stream) {
+    if (!z || !gamma || !dh || !dz || !dparams || !workspace || R < 1) return kEINVAL;
     Shape sh;
     if (!pick_shape(H, sh)) return kEUNSUPPORTED;
-    if (sh.vec == 4 && !(aligned16(z) && aligned16(dh) && aligned16(dz) && aligned16(gamma) && aligned16(workspace)))
+    if (sh.vec == 4 && !(aligned16(z) && aligned16(dh) && aligned16(dz) && aligned16(gamma) && aligned16(workspace) &&
+                         aligned16(bias)))
         return kEINVAL;
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
     const int grid = (int)waves_for(R, kReluLnBlocks);
-    LAUNCH_SHAPE(relu_ln_bwd_k, grid, 0, z, gamma, dh, eps, dz, workspace, (long long)R, (int)H);
-    const int P = 2 * H;
+    LAUNCH_SHAPE(relu_ln_bwd_k, grid, 0, z, bias, gamma, dh, eps, dz, workspace, (long long)R, (int)H);
+    const int P = 3 * H;
     hipLaunchKernelGGL(reduce_partials_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace,
-                       (long long)grid * kWavesPerBlock, P, dgamma);
+                       (long long)grid * kWavesPerBlock, P, P, dparams);
+    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+}
+
+DCC_API int dcc_relu_ln_head_fwd(const float* z, const float* bias, const float* gamma, const float* beta, float eps,
+                                 const float* Wo, const float* bo, float* y, int64_t R, int32_t H, int32_t A,
+                                 void* stream) {
+    if (!z || !gamma || !beta || !Wo || !y || R < 0) return kEINVAL;
+    Shape sh;
+    if (!pick_shape(H, sh) || A < 1 || A > kAMax) return kEUNSUPPORTED;
+    if (sh.vec == 4 && !(aligned16(z) && aligned16(gamma) && aligned16(beta) && aligned16(Wo))) return kEINVAL;
+    if (R == 0) return 0;
+    hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
+    const int grid = (int)waves_for(R, kReluLnBlocks);
+    LAUNCH_SHAPE(relu_ln_head_fwd_k, grid, 0, z, bias, gamma, beta, eps, Wo, bo, y, (long long)R, (int)H, (int)A);
+    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+}
+
+DCC_API int dcc_relu_ln_head_bwd(const float* z, const float* bias, const float* gamma, const float* beta, float eps,
+                                 const float* Wo, const float* dy, float* dz, float* dparams, float* workspace, int64_t R,
+                                 int32_t H, int32_t A, void* stream) {
+    if (!z || !gamma || !beta || !Wo || !dy || !dz || !dparams || !workspace || R < 1) return kEINVAL;
+    Shape sh;
+    if (!pick_shape(H, sh) || A < 1 || A > kAMax) return kEUNSUPPORTED;
+    if (sh.vec == 4 && !(aligned16(z) && aligned16(dz) && aligned16(gamma) && aligned16(beta) && aligned16(Wo) &&
+                         aligned16(workspace)))
+        return kEINVAL;
+    hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
+    const int grid = (int)waves_for(R, kReluLnBlocks);
+    LAUNCH_SHAPE(relu_ln_head_bwd_k, grid, 0, z, bias, gamma, beta, eps, Wo, dy, dz, workspace, (long long)R, (int)H, (int)A);
+    const int P = (3 + A) * H;
+    hipLaunchKernelGGL(reduce_partials_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace,
+                       (long long)grid * kWavesPerBlock, P, (3 + kAMax) * (int)H, dparams);
     return hipGetLastError() == hipSuccess ? 0 : kEHIP;
 }
 

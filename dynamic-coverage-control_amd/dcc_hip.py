@@ -43,7 +43,7 @@ class EnvOut(ctypes.Structure):
 EXPORTS = ["dcc_obs_expand", "dcc_gae_compute", "dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
            "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout", "dcc_env_get_state",
            "dcc_env_set_state", "dcc_env_bytes_per_step", "dcc_obs_features",
-           "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd"]
+           "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_relu_ln_head_fwd", "dcc_relu_ln_head_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd"]
 
 _lib = None
 
@@ -78,8 +78,10 @@ def load_library(path=None):
     L.dcc_obs_expand.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]
     L.dcc_obs_features.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     f32, i32, i64 = ctypes.c_float, ctypes.c_int32, ctypes.c_int64
-    L.dcc_relu_ln_fwd.argtypes = [_vp, _vp, _vp, f32, _vp, i64, i32, _vp]
-    L.dcc_relu_ln_bwd.argtypes = [_vp, _vp, _vp, f32, _vp, _vp, _vp, _vp, i64, i32, _vp]
+    L.dcc_relu_ln_fwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, i64, i32, _vp]
+    L.dcc_relu_ln_bwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, _vp, _vp, i64, i32, _vp]
+    L.dcc_relu_ln_head_fwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, _vp, _vp, i64, i32, i32, _vp]
+    L.dcc_relu_ln_head_bwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, _vp, _vp, _vp, _vp, i64, i32, i32, _vp]
     L.dcc_mlp_workspace_floats.argtypes = [i32, i32]
     L.dcc_mlp_workspace_floats.restype = i64
     L.dcc_actor_l1_fwd.argtypes = [_vp] * 8 + [f32, f32, i32, _vp, i64, i32, i32, i32, _vp]
@@ -342,25 +344,54 @@ def _f32c(t, name):
     return t
 
 
-def relu_ln_fwd(z, gamma, beta, eps):
+def relu_ln_fwd(z, bias, gamma, beta, eps):
+    """h = LayerNorm(ReLU(z + bias)); bias may be None."""
     R, H = z.shape
     h = torch.empty_like(_f32c(z, "z"))
     with torch.cuda.device(z.device):
-        _check(load_library().dcc_relu_ln_fwd(_ptr(z), _ptr(_f32c(gamma, "gamma")), _ptr(_f32c(beta, "beta")), eps, _ptr(h),
-                                              R, H, _stream()), "dcc_relu_ln_fwd")
+        _check(load_library().dcc_relu_ln_fwd(_ptr(z), _ptr(bias), _ptr(_f32c(gamma, "gamma")), _ptr(_f32c(beta, "beta")), eps,
+                                              _ptr(h), R, H, _stream()), "dcc_relu_ln_fwd")
     return h
 
 
-def relu_ln_bwd(z, gamma, dh, eps):
+def relu_ln_bwd(z, bias, gamma, dh, eps):
+    """-> dz, dgamma, dbeta, dbias (column sums of dz)."""
     R, H = z.shape
     L = load_library()
     dz = torch.empty_like(_f32c(z, "z"))
-    dgb = torch.empty((2, H), dtype=torch.float32, device=z.device)
+    dp = torch.empty((3, H), dtype=torch.float32, device=z.device)
     ws = torch.empty(L.dcc_mlp_workspace_floats(H, 0), dtype=torch.float32, device=z.device)
     with torch.cuda.device(z.device):
-        _check(L.dcc_relu_ln_bwd(_ptr(z), _ptr(_f32c(gamma, "gamma")), _ptr(_f32c(dh, "dh")), eps, _ptr(dz), _ptr(dgb[0]),
-                                 _ptr(dgb[1]), _ptr(ws), R, H, _stream()), "dcc_relu_ln_bwd")
-    return dz, dgb[0], dgb[1]
+        _check(L.dcc_relu_ln_bwd(_ptr(z), _ptr(bias), _ptr(_f32c(gamma, "gamma")), _ptr(_f32c(dh, "dh")), eps, _ptr(dz),
+                                 _ptr(dp), _ptr(ws), R, H, _stream()), "dcc_relu_ln_bwd")
+    return dz, dp[0], dp[1], dp[2]
+
+
+def relu_ln_head_fwd(z, bias, gamma, beta, eps, Wo, bo):
+    """y [R,A] = LayerNorm(ReLU(z + bias)) Wo^T + bo (A <= 4)."""
+    R, H = z.shape
+    A = Wo.shape[0]
+    y = torch.empty((R, A), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        _check(load_library().dcc_relu_ln_head_fwd(_ptr(_f32c(z, "z")), _ptr(bias), _ptr(_f32c(gamma, "gamma")),
+                                                   _ptr(_f32c(beta, "beta")), eps, _ptr(_f32c(Wo, "Wo")), _ptr(bo), _ptr(y),
+                                                   R, H, A, _stream()), "dcc_relu_ln_head_fwd")
+    return y
+
+
+def relu_ln_head_bwd(z, bias, gamma, beta, eps, Wo, dy):
+    """-> dz [R,H], dgamma [H], dbeta [H], dbias [H], dWo [A,H]."""
+    R, H = z.shape
+    A = Wo.shape[0]
+    L = load_library()
+    dz = torch.empty_like(z)
+    dp = torch.empty((3 + A, H), dtype=torch.float32, device=z.device)
+    ws = torch.empty(L.dcc_mlp_workspace_floats(H, 0), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        _check(L.dcc_relu_ln_head_bwd(_ptr(_f32c(z, "z")), _ptr(bias), _ptr(_f32c(gamma, "gamma")), _ptr(_f32c(beta, "beta")),
+                                      eps, _ptr(_f32c(Wo, "Wo")), _ptr(_f32c(dy, "dy")), _ptr(dz), _ptr(dp), _ptr(ws), R, H, A,
+                                      _stream()), "dcc_relu_ln_head_bwd")
+    return dz, dp[0], dp[1], dp[2], dp[3:]
 
 
 def actor_l1_fwd(head, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, D):

@@ -10,6 +10,8 @@
  *
  *   dcc_relu_ln_fwd / _bwd      h = LayerNorm(ReLU(z))   one read + one write;  backward recomputes the
  *                               LayerNorm statistics from z instead of storing them
+ *   dcc_relu_ln_head_fwd / _bwd the last block's tail fused with the narrow output layer that follows it (action
+ *                               mean / value): y = LayerNorm(ReLU(z)) Wo^T + bo; h is never stored
  *   dcc_actor_l1_fwd / _bwd     the actor's first block evaluated straight from the compact features of
  *                               dcc_obs_features (include/dcc_env.h):
  *                                   z = rstd_in * (head . Wh^T + G[env] - mean_in * s) + c ;  h = LayerNorm(ReLU(z))
@@ -37,16 +39,31 @@ extern "C" {
 #endif
 #endif
 
-/* h[R,H] = LayerNorm_{gamma,beta,eps}(max(z, 0)) over the last axis (mlp.py:13-16 block tail: ReLU -> LayerNorm). */
-DCC_API int dcc_relu_ln_fwd(const float* z, const float* gamma, const float* beta, float eps, float* h, int64_t R,
-                            int32_t H, void* stream);
+/* h[R,H] = LayerNorm_{gamma,beta,eps}(max(z + bias, 0)) over the last axis (mlp.py:13-16 block tail: the Linear's bias
+ * add, ReLU, LayerNorm); bias [H] may be NULL. */
+DCC_API int dcc_relu_ln_fwd(const float* z, const float* bias, const float* gamma, const float* beta, float eps, float* h,
+                            int64_t R, int32_t H, void* stream);
 
 /* Floats of workspace the backward calls below need for a given problem (0 if unsupported). */
 DCC_API int64_t dcc_mlp_workspace_floats(int32_t H, int32_t HD);
 
-/* Given dh = dL/dh: dz[R,H] = dL/dz, dgamma[H], dbeta[H] (written, not accumulated). */
-DCC_API int dcc_relu_ln_bwd(const float* z, const float* gamma, const float* dh, float eps, float* dz, float* dgamma,
-                            float* dbeta, float* workspace, int64_t R, int32_t H, void* stream);
+/* Given dh = dL/dh: dz[R,H] = dL/dz; dparams [3,H] = rows dgamma, dbeta, dbias (= column sums of dz, i.e. the gradient of
+ * the producing Linear's bias, free here) -- written, not accumulated. */
+DCC_API int dcc_relu_ln_bwd(const float* z, const float* bias, const float* gamma, const float* dh, float eps, float* dz,
+                            float* dparams, float* workspace, int64_t R, int32_t H, void* stream);
+
+/* y[R,A] = LayerNorm(ReLU(z + bias)) . Wo^T + bo for a narrow head (A <= 4: the Gaussian mean, distributions.py:83-92
+ * fc_mean, or the value head, r_actor_critic.py:109 v_out) -- the normalised activations are not stored.  bias and bo may
+ * be NULL. */
+DCC_API int dcc_relu_ln_head_fwd(const float* z, const float* bias, const float* gamma, const float* beta, float eps,
+                                 const float* Wo, const float* bo, float* y, int64_t R, int32_t H, int32_t A,
+                                 void* stream);
+
+/* Backward given dy [R,A]: dz [R,H]; dparams [(3+A),H] = rows dgamma, dbeta, dbias, dWo[0..A-1] (d bo = column sums of dy
+ * is left to the caller). */
+DCC_API int dcc_relu_ln_head_bwd(const float* z, const float* bias, const float* gamma, const float* beta, float eps,
+                                 const float* Wo, const float* dy, float* dz, float* dparams, float* workspace, int64_t R,
+                                 int32_t H, int32_t A, void* stream);
 
 /*
  * Actor first block from compact features of n env states with N agents each (rows r = e*N + i):

@@ -37,24 +37,32 @@ def test_relu_ln_matches_torch(R, H):
         ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-0.5, 0.5)
     assert dcc_hip.mlp_fused_supported(H)
     dh = torch.randn(R, H, device=dev, generator=g)
-    z1 = z.clone().requires_grad_(True)
-    h1 = fused.relu_ln(z1, ln)
-    assert h1.grad_fn is not None and "ReluLN" in type(h1.grad_fn).__name__      # the HIP path ran, not the fallback
-    h1.backward(dh)
-    g1 = (z1.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone())
-    ln.zero_grad()
-    z2 = z.clone().requires_grad_(True)
-    h2 = ln(torch.relu(z2))
-    h2.backward(dh)
-    _close(h1.detach(), h2.detach(), "h")
-    _close(g1[0], z2.grad, "dz")
-    _close(g1[1], ln.weight.grad, "dgamma", rtol=1e-4, atol=1e-5)
-    _close(g1[2], ln.bias.grad, "dbeta", rtol=1e-4, atol=1e-5)
-    # deterministic: same bits on a second run
-    ln.zero_grad()
-    z3 = z.clone().requires_grad_(True)
-    fused.relu_ln(z3, ln).backward(dh)
-    assert torch.equal(z3.grad, g1[0]) and torch.equal(ln.weight.grad, g1[1]) and torch.equal(ln.bias.grad, g1[2])
+    for with_bias in (False, True):
+        bias = (torch.randn(H, device=dev, generator=g) * 0.5).requires_grad_(True) if with_bias else None
+        ln.zero_grad()
+        z1 = z.clone().requires_grad_(True)
+        h1 = fused.relu_ln(z1, bias, ln)
+        assert h1.grad_fn is not None and "ReluLN" in type(h1.grad_fn).__name__      # the HIP path ran, not the fallback
+        h1.backward(dh)
+        g1 = (z1.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone(), bias.grad.clone() if with_bias else None)
+        ln.zero_grad()
+        if with_bias:
+            bias.grad = None
+        z2 = z.clone().requires_grad_(True)
+        h2 = ln(torch.relu(z2 + bias if with_bias else z2))
+        h2.backward(dh)
+        _close(h1.detach(), h2.detach(), "h")
+        _close(g1[0], z2.grad, "dz")
+        _close(g1[1], ln.weight.grad, "dgamma", rtol=1e-4, atol=1e-5)
+        _close(g1[2], ln.bias.grad, "dbeta", rtol=1e-4, atol=1e-5)
+        if with_bias:
+            _close(g1[3], bias.grad, "dbias", rtol=1e-4, atol=1e-5)
+            bias.grad = None
+        # deterministic: same bits on a second run
+        ln.zero_grad()
+        z3 = z.clone().requires_grad_(True)
+        fused.relu_ln(z3, bias, ln).backward(dh)
+        assert torch.equal(z3.grad, g1[0]) and torch.equal(ln.weight.grad, g1[1]) and torch.equal(ln.bias.grad, g1[2])
 
 
 def test_unsupported_width_falls_back_to_torch_ops():
@@ -64,7 +72,7 @@ def test_unsupported_width_falls_back_to_torch_ops():
     assert not dcc_hip.mlp_fused_supported(1000) and not dcc_hip.mlp_fused_supported(130)
     ln = torch.nn.LayerNorm(130).to(dev)
     z = torch.randn(7, 130, device=dev, requires_grad=True)
-    h = fused.relu_ln(z, ln)
+    h = fused.relu_ln(z, None, ln)
     assert "ReluLN" not in type(h.grad_fn).__name__
     assert torch.equal(h, ln(torch.relu(z)))
 
@@ -132,5 +140,66 @@ def test_shapes_outside_the_compiled_variants_are_refused():
     assert L.dcc_mlp_workspace_floats(1000, 0) == 0 and L.dcc_mlp_workspace_floats(256, 41) == 0
     z = torch.zeros(4, 1000, device="cuda")
     v = torch.zeros(1000, device="cuda")
-    rc = L.dcc_relu_ln_fwd(z.data_ptr(), v.data_ptr(), v.data_ptr(), 1e-5, z.data_ptr(), 4, 1000, None)
+    rc = L.dcc_relu_ln_fwd(z.data_ptr(), None, v.data_ptr(), v.data_ptr(), 1e-5, z.data_ptr(), 4, 1000, None)
     assert rc == -4
+
+
+@pytest.mark.parametrize("R,H,A", [(4099, 256, 2), (3000, 256, 1), (77, 64, 2), (5, 32, 4), (301, 128, 3), (50, 100, 1)])
+def test_relu_ln_head_matches_torch(R, H, A):
+    """head(LayerNorm(ReLU(z))) with a narrow head (Gaussian mean A=2, value head A=1): output, dz and every
+    parameter gradient against the unfused torch ops; bit-reproducible."""
+    from algos.algo_utils import fused
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(R + H + A)
+    z = torch.randn(R, H, device=dev, generator=g) * 1.3 + 0.1
+    ln = torch.nn.LayerNorm(H).to(dev)
+    head = torch.nn.Linear(H, A).to(dev)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-0.5, 0.5); head.bias.uniform_(-1, 1)
+    dy = torch.randn(R, A, device=dev, generator=g)
+    zbias = (torch.randn(H, device=dev, generator=g) * 0.5).requires_grad_(True)
+    params = list(ln.parameters()) + list(head.parameters()) + [zbias]
+
+    def run(enabled):
+        fused.ENABLED = enabled
+        try:
+            for p in params:
+                p.grad = None
+            zz = z.clone().requires_grad_(True)
+            y = fused.relu_ln_head(zz, zbias, ln, head)
+            if enabled:
+                assert "ReluLNHead" in type(y.grad_fn).__name__
+            y.backward(dy)
+            return y.detach().clone(), zz.grad.clone(), [p.grad.clone() for p in params]
+        finally:
+            fused.ENABLED = True
+
+    y1, dz1, g1 = run(True)
+    y2, dz2, g2 = run(False)
+    _close(y1, y2, "y", rtol=1e-4, atol=1e-5)
+    _close(dz1, dz2, "dz", rtol=1e-4, atol=1e-5)
+    for name, a, b in zip(("ln.weight", "ln.bias", "head.weight", "head.bias", "zbias"), g1, g2):
+        _close(a, b, name, rtol=2e-4, atol=2e-5)
+    y3, dz3, g3 = run(True)
+    assert torch.equal(y1, y3) and torch.equal(dz1, dz3) and all(torch.equal(a, b) for a, b in zip(g1, g3))
+
+
+@pytest.mark.parametrize("R,K,H", [(4915200 // 8, 256, 256), (65536 + 128 * 3, 18, 64), (70001, 40, 32)])
+def test_split_k_linear_matches_plain(R, K, H):
+    """The bias-free Linear with the batched (split-K) weight gradient == F.linear / autograd."""
+    from algos.algo_utils import fused
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(R % 1000)
+    x = torch.randn(R, K, device=dev, generator=g)
+    W = torch.randn(H, K, device=dev, generator=g)
+    dz = torch.randn(R, H, device=dev, generator=g)
+    x1, W1 = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    y1 = fused.linear_w(x1, W1)
+    assert "LinearSplitK" in type(y1.grad_fn).__name__
+    y1.backward(dz)
+    x2, W2 = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    y2 = torch.nn.functional.linear(x2, W2)
+    y2.backward(dz)
+    assert torch.equal(y1, y2)
+    _close(x1.grad, x2.grad, "dx", rtol=1e-5, atol=1e-6)
+    _close(W1.grad, W2.grad, "dW", rtol=1e-4, atol=1e-5)
