@@ -12,6 +12,11 @@
 
 #include "dcc_mlp.h"
 
+// The Makefile builds the library with -ffp-contract=off for the env kernel's float64 parity; nothing here is
+// compared bit-for-bit with a CPU (the tests use tolerances), and these kernels are VALU-bound without fused
+// multiply-adds, so contraction is switched back on for this file.
+#pragma clang fp contract(fast)
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -19,10 +24,22 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kReluLnBlocks = 1024;   // 4096 waves: 16 per CU
 constexpr int kL1Blocks = 512;        // 2048 waves (the L1 backward keeps ~100 accumulators per lane)
 
+// Wave-wide sum, result in every lane.  Four DPP adds (VALU, no LDS round trip) leave each 16-lane row with its row
+// sum; the four row sums are combined through readlane.  (__shfl_xor compiles to ds_bpermute: six dependent LDS
+// round trips per reduction.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 }
 
 template <int VEC>
@@ -70,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void relu_ln_fwd_k(const float* __restrict_
                                                         const float* __restrict__ beta, float eps,
                                                         float* __restrict__ h, long long R, int H) {
     const int lane = threadIdx.x & 63;
-    const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long nw = (long long)gridDim.x * kWavesPerBlock;
     float g[VPL][VEC], b[VPL][VEC], zb[VPL][VEC];
     bool ok[VPL];
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void relu_ln_bwd_k(const float* __restrict_
                                                         float* __restrict__ dz, float* __restrict__ ws, long long R,
                                                         int H) {
     const int lane = threadIdx.x & 63;
-    const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long nw = (long long)gridDim.x * kWavesPerBlock;
     float g[VPL][VEC], zb[VPL][VEC], acc_g[VPL][VEC], acc_b[VPL][VEC], acc_z[VPL][VEC];
     bool ok[VPL];
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void relu_ln_head_fwd_k(const float* __rest
                                                              const float* __restrict__ Wo, const float* __restrict__ bo,
                                                              float* __restrict__ y, long long R, int H, int A) {
     const int lane = threadIdx.x & 63;
-    const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long nw = (long long)gridDim.x * kWavesPerBlock;
     float g[VPL][VEC], b[VPL][VEC], zb[VPL][VEC], wo[kAMax][VPL][VEC];
     bool ok[VPL];
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void relu_ln_head_bwd_k(const float* __rest
                                                              float* __restrict__ dz, float* __restrict__ ws, long long R,
                                                              int H, int A) {
     const int lane = threadIdx.x & 63;
-    const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long nw = (long long)gridDim.x * kWavesPerBlock;
     float g[VPL][VEC], b[VPL][VEC], zb[VPL][VEC], wo[kAMax][VPL][VEC];
     float acc_g[VPL][VEC], acc_b[VPL][VEC], acc_z[VPL][VEC], acc_w[kAMax][VPL][VEC];
@@ -336,6 +353,26 @@ __global__ __launch_bounds__(kBlock) void relu_ln_head_bwd_k(const float* __rest
         }
 }
 
+// Stage 1 of the partial-sum reduction: the nw per-wave vectors are cut into gridDim.y segments of `seg` waves; every
+// segment is summed (fixed order) into its own first slot, in place.  Stage 2 (reduce_partials_k / l1_reduce_k with
+// nw = number of segments and stride = seg * stride) adds the segment sums.  One thread per column p, so no two
+// threads touch the same address.
+__global__ __launch_bounds__(kBlock) void reduce_segments_k(float* __restrict__ ws, long long nw, int seg, int P, int stride) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const long long w0 = (long long)blockIdx.y * seg;
+    long long w1 = w0 + seg;
+    if (w1 > nw) w1 = nw;
+    if (w0 >= w1) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long long w = w0;
+    for (; w + 3 < w1; w += 4) {
+        s0 += ws[w * stride + p]; s1 += ws[(w + 1) * stride + p]; s2 += ws[(w + 2) * stride + p]; s3 += ws[(w + 3) * stride + p];
+    }
+    for (; w < w1; ++w) s0 += ws[w * stride + p];
+    ws[w0 * stride + p] = (s0 + s1) + (s2 + s3);
+}
+
 // out[p] = sum over the nw per-wave partial vectors (fixed order).
 __global__ __launch_bounds__(kBlock) void reduce_partials_k(const float* __restrict__ ws, long long nw, int P, int stride,
                                                             float* __restrict__ out) {
@@ -388,7 +425,7 @@ __device__ __forceinline__ void in_stats(const double* __restrict__ stats, long 
     if (stats) {
         const double m = stats[2 * r], m2 = stats[2 * r + 1];
         mean_in = (float)m;
-        rstd_in = (float)(1.0 / sqrt(m2 / (double)D + (double)eps_in));
+        rstd_in = 1.0f / sqrtf((float)(m2 * (1.0 / (double)D)) + eps_in);
     }
 }
 
@@ -404,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void actor_l1_fwd_k(const float* __restrict
     for (int i = threadIdx.x; i < HD * H; i += kBlock) { const int k = i / H, cc = i - k * H; Wt[i] = Wh[cc * HD + k]; }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long nw = (long long)gridDim.x * kWavesPerBlock;
     float g[VPL][VEC], b[VPL][VEC], sv[VPL][VEC], cv[VPL][VEC];
     bool ok[VPL];
@@ -418,6 +455,13 @@ __global__ __launch_bounds__(kBlock) void actor_l1_fwd_k(const float* __restrict
         if (ok[v]) { ld<VEC>(gamma + cb[v], g[v]); ld<VEC>(beta + cb[v], b[v]); ld<VEC>(s + cb[v], sv[v]); ld<VEC>(c + cb[v], cv[v]); }
     }
     const float invH = 1.0f / (float)H;
+    float nhv = 0.f;
+    double nm = 0.0, nm2 = 0.0;
+    auto fetch = [&](long long r) {
+        nhv = lane < HD ? head[r * HD + lane] : 0.f;
+        if (stats) { nm = stats[2 * r]; nm2 = stats[2 * r + 1]; }
+    };
+    if (gw < n) fetch(gw * N);
     for (long long e = gw; e < n; e += nw) {
         float Gv[VPL][VEC];
 #pragma unroll
@@ -428,9 +472,11 @@ __global__ __launch_bounds__(kBlock) void actor_l1_fwd_k(const float* __restrict
         }
         for (int i = 0; i < N; ++i) {
             const long long r = e * N + i;
-            const float hv = lane < HD ? head[r * HD + lane] : 0.f;
-            float mean_in, rstd_in;
-            in_stats(stats, r, D, eps_in, mean_in, rstd_in);
+            const float hv = nhv;
+            float mean_in = 0.f, rstd_in = 1.f;
+            if (stats) { mean_in = (float)nm; rstd_in = 1.0f / sqrtf((float)(nm2 * (1.0 / (double)D)) + eps_in); }
+            const long long rn = (i + 1 < N) ? r + 1 : ((e + nw < n) ? (e + nw) * N : -1);
+            if (rn >= 0) fetch(rn);     // the next row's head values / moments travel while this row is computed
             float a[VPL][VEC];
             l1_row_z<VEC, VPL>(Wt, H, HD, hv, mean_in, rstd_in, Gv, sv, cv, cb, ok, a);
 #pragma unroll
@@ -464,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
     for (int i = threadIdx.x; i < HD * H; i += kBlock) { const int k = i / H, cc = i - k * H; Wt[i] = Wh[cc * HD + k]; }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const long long gw = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long nw = (long long)gridDim.x * kWavesPerBlock;
     float g[VPL][VEC], sv[VPL][VEC], cv[VPL][VEC];
     float acc_g[VPL][VEC], acc_b[VPL][VEC], acc_s[VPL][VEC], acc_c[VPL][VEC], acc_w[HDP][VPL][VEC];
@@ -488,21 +534,31 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc_w[k][v][j] = 0.f;
     const float invH = 1.0f / (float)H;
-    // software pipeline: the loads of the next row (dh, head, input moments) are issued before the current row is
-    // processed -- with ~100 accumulator registers per lane only two waves fit a SIMD, too few to hide HBM latency
-    float nd[VPL][VEC], nhv = 0.f;
-    double nm = 0.0, nm2 = 0.0;
-    auto fetch = [&](long long r) {
+    // software pipeline, two rows deep: with ~100 accumulator registers per lane only two waves fit a SIMD, far too
+    // few to hide HBM latency, so the loads of row t+2 (dh, head, input moments) are issued before row t is processed
+    float nd[2][VPL][VEC], nhv[2] = {0.f, 0.f};
+    double nm[2] = {0.0, 0.0}, nm2[2] = {0.0, 0.0};
+    auto fetch = [&](long long r, float (&dd)[VPL][VEC], float& hv_, double& m_, double& m2_) {
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) nd[v][j] = 0.f;
-            if (ok[v]) ld<VEC>(dh + r * H + cb[v], nd[v]);
+            for (int j = 0; j < VEC; ++j) dd[v][j] = 0.f;
+            if (ok[v]) ld<VEC>(dh + r * H + cb[v], dd[v]);
         }
-        nhv = lane < HD ? head[r * HD + lane] : 0.f;
-        if (stats) { nm = stats[2 * r]; nm2 = stats[2 * r + 1]; }
+        hv_ = lane < HD ? head[r * HD + lane] : 0.f;
+        if (stats) { m_ = stats[2 * r]; m2_ = stats[2 * r + 1]; }
     };
-    if (gw < n) fetch(gw * N);
+    // look-ahead cursor over this wave's row order (e, 0..N-1), (e + nw, 0..N-1), ...: (pe, pi) is the next row to fetch
+    long long pe = gw;
+    int pi = 0;
+    auto fetch_next = [&](float (&dd)[VPL][VEC], float& hv_, double& m_, double& m2_) {
+        if (pe < n) {
+            fetch(pe * N + pi, dd, hv_, m_, m2_);
+            if (++pi == N) { pi = 0; pe += nw; }
+        }
+    };
+    fetch_next(nd[0], nhv[0], nm[0], nm2[0]);
+    fetch_next(nd[1], nhv[1], nm[1], nm2[1]);
     for (long long e = gw; e < n; e += nw) {
         float Gv[VPL][VEC], dGv[VPL][VEC];
 #pragma unroll
@@ -512,17 +568,16 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
             if (ok[v]) ld<VEC>(G + e * H + cb[v], Gv[v]);
         }
         for (int i = 0; i < N; ++i) {
-            const long long r = e * N + i;
             float d[VPL][VEC];
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) d[v][j] = nd[v][j];
-            const float hv = nhv;
+                for (int j = 0; j < VEC; ++j) { d[v][j] = nd[0][v][j]; nd[0][v][j] = nd[1][v][j]; }
+            const float hv = nhv[0];
             float mean_in = 0.f, rstd_in = 1.f;
-            if (stats) { mean_in = (float)nm; rstd_in = (float)(1.0 / sqrt(nm2 / (double)D + (double)eps_in)); }
-            const long long rn = (i + 1 < N) ? r + 1 : ((e + nw < n) ? (e + nw) * N : -1);
-            if (rn >= 0) fetch(rn);
+            if (stats) { mean_in = (float)nm[0]; rstd_in = 1.0f / sqrtf((float)(nm2[0] * (1.0 / (double)D)) + eps_in); }
+            nhv[0] = nhv[1]; nm[0] = nm[1]; nm2[0] = nm2[1];
+            fetch_next(nd[1], nhv[1], nm[1], nm2[1]);   // row t+2 (row t+1 is already in flight)
             float zr[VPL][VEC], a[VPL][VEC];
             l1_row_z<VEC, VPL>(Wt, H, HD, hv, mean_in, rstd_in, Gv, sv, cv, cb, ok, zr);
 #pragma unroll
@@ -572,7 +627,7 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
 }
 
 // partial layout [k][c] -> dWh [c][k], plus the four H-vectors
-__global__ __launch_bounds__(kBlock) void l1_reduce_k(const float* __restrict__ ws, long long nw, int HDP, int HD, int H,
+__global__ __launch_bounds__(kBlock) void l1_reduce_k(const float* __restrict__ ws, long long nw, long long wstride, int HDP, int HD, int H,
                                                       float* __restrict__ dWh, float* __restrict__ ds,
                                                       float* __restrict__ dc, float* __restrict__ dgamma,
                                                       float* __restrict__ dbeta) {
@@ -584,9 +639,9 @@ __global__ __launch_bounds__(kBlock) void l1_reduce_k(const float* __restrict__ 
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     long long w = 0;
     for (; w + 3 < nw; w += 4) {
-        s0 += ws[w * P + p]; s1 += ws[(w + 1) * P + p]; s2 += ws[(w + 2) * P + p]; s3 += ws[(w + 3) * P + p];
+        s0 += ws[w * wstride + p]; s1 += ws[(w + 1) * wstride + p]; s2 += ws[(w + 2) * wstride + p]; s3 += ws[(w + 3) * wstride + p];
     }
-    for (; w < nw; ++w) s0 += ws[w * P + p];
+    for (; w < nw; ++w) s0 += ws[w * wstride + p];
     const float t = (s0 + s1) + (s2 + s3);
     if (k < HDP) dWh[cc * HD + k] = t;
     else if (k == HDP) ds[cc] = t;
@@ -634,6 +689,15 @@ void launch_l1_bwd(const Shape& sh, int grid, size_t lds, hipStream_t st_, A... 
     else hipLaunchKernelGGL((actor_l1_bwd_k<1, 2, HDP>), dim3(grid), dim3(kBlock), lds, st_, a...);
 }
 
+constexpr int kSegWaves = 64;   // waves per stage-1 segment of the partial-sum reduction
+// stage 1 in place; returns the number of segments (the "waves" stage 2 sees, at stride kSegWaves * stride)
+long long reduce_stage1(float* ws, long long nw, int P, int stride, hipStream_t st_) {
+    const long long nseg = (nw + kSegWaves - 1) / kSegWaves;
+    hipLaunchKernelGGL(reduce_segments_k, dim3((P + kBlock - 1) / kBlock, (unsigned)nseg), dim3(kBlock), 0, st_, ws, nw,
+                       kSegWaves, P, stride);
+    return nseg;
+}
+
 constexpr int kEINVAL = -1, kEHIP = -2, kEUNSUPPORTED = -4;
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -676,8 +740,9 @@ DCC_API int dcc_relu_ln_bwd(const float* z, const float* bias, const float* gamm
     const int grid = (int)waves_for(R, kReluLnBlocks);
     LAUNCH_SHAPE(relu_ln_bwd_k, grid, 0, z, bias, gamma, dh, eps, dz, workspace, (long long)R, (int)H);
     const int P = 3 * H;
-    hipLaunchKernelGGL(reduce_partials_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace,
-                       (long long)grid * kWavesPerBlock, P, P, dparams);
+    const long long nseg = reduce_stage1(workspace, (long long)grid * kWavesPerBlock, P, P, st_);
+    hipLaunchKernelGGL(reduce_partials_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace, nseg, P,
+                       kSegWaves * P, dparams);
     return hipGetLastError() == hipSuccess ? 0 : kEHIP;
 }
 
@@ -707,9 +772,10 @@ DCC_API int dcc_relu_ln_head_bwd(const float* z, const float* bias, const float*
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
     const int grid = (int)waves_for(R, kReluLnBlocks);
     LAUNCH_SHAPE(relu_ln_head_bwd_k, grid, 0, z, bias, gamma, beta, eps, Wo, dy, dz, workspace, (long long)R, (int)H, (int)A);
-    const int P = (3 + A) * H;
-    hipLaunchKernelGGL(reduce_partials_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace,
-                       (long long)grid * kWavesPerBlock, P, (3 + kAMax) * (int)H, dparams);
+    const int P = (3 + A) * H, stride = (3 + kAMax) * (int)H;
+    const long long nseg = reduce_stage1(workspace, (long long)grid * kWavesPerBlock, P, stride, st_);
+    hipLaunchKernelGGL(reduce_partials_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace, nseg, P,
+                       kSegWaves * stride, dparams);
     return hipGetLastError() == hipSuccess ? 0 : kEHIP;
 }
 
@@ -754,8 +820,9 @@ DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* st
         default: launch_l1_bwd<40>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
     }
     const int P = (hdp + 4) * H;
-    hipLaunchKernelGGL(l1_reduce_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace,
-                       (long long)grid * kWavesPerBlock, hdp, (int)HD, (int)H, dWh, ds, dc, dgamma, dbeta);
+    const long long nseg = reduce_stage1(workspace, (long long)grid * kWavesPerBlock, P, P, st_);
+    hipLaunchKernelGGL(l1_reduce_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace, nseg,
+                       (long long)kSegWaves * P, hdp, (int)HD, (int)H, dWh, ds, dc, dgamma, dbeta);
     return hipGetLastError() == hipSuccess ? 0 : kEHIP;
 }
 
