@@ -497,15 +497,16 @@ __global__ __launch_bounds__(kBlock) void actor_l1_fwd_k(const float* __restrict
     }
 }
 
-// per-wave partial vector of the L1 backward: [dWt (HDP*H) | ds (H) | dc (H) | dgamma (H) | dbeta (H)]
+// per-wave partial vector of the L1 backward: [dWt (HDP*H) | ds (H) | dc (H) | dgamma (H) | dbeta (H)].
+// HDP = 0: no dWh accumulators (they are what limits the kernel to 2 waves/SIMD); q = rstd_in * dz is stored instead.
 template <int VEC, int VPL, int HDP>
 __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict__ head, const float* __restrict__ G,
                                                          const double* __restrict__ stats,
                                                          const float* __restrict__ Wh, const float* __restrict__ s,
                                                          const float* __restrict__ c, const float* __restrict__ gamma,
                                                          const float* __restrict__ dh, float eps_in, float eps_ln,
-                                                         int D, float* __restrict__ dG, float* __restrict__ ws,
-                                                         long long n, int N, int HD, int H) {
+                                                         int D, float* __restrict__ dG, float* __restrict__ dq,
+                                                         float* __restrict__ ws, long long n, int N, int HD, int H) {
     extern __shared__ __attribute__((aligned(16))) float Wt[];   // [HD][H]
     for (int i = threadIdx.x; i < HD * H; i += kBlock) { const int k = i / H, cc = i - k * H; Wt[i] = Wh[cc * HD + k]; }
     __syncthreads();
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
     const long long gw = (long long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long nw = (long long)gridDim.x * kWavesPerBlock;
     float g[VPL][VEC], sv[VPL][VEC], cv[VPL][VEC];
-    float acc_g[VPL][VEC], acc_b[VPL][VEC], acc_s[VPL][VEC], acc_c[VPL][VEC], acc_w[HDP][VPL][VEC];
+    float acc_g[VPL][VEC], acc_b[VPL][VEC], acc_s[VPL][VEC], acc_c[VPL][VEC], acc_w[HDP > 0 ? HDP : 1][VPL][VEC];
     bool ok[VPL];
     int cb[VPL];
 #pragma unroll
@@ -568,6 +569,7 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
             if (ok[v]) ld<VEC>(G + e * H + cb[v], Gv[v]);
         }
         for (int i = 0; i < N; ++i) {
+            const long long r = e * N + i;
             float d[VPL][VEC];
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
@@ -597,6 +599,11 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
                     acc_s[v][j] -= mean_in * q[v][j];
                     acc_c[v][j] += d[v][j];
                 }
+            if constexpr (HDP == 0) {   // two-kernel variant: q goes to memory, the caller forms dWh = q^T head as a GEMM
+#pragma unroll
+                for (int v = 0; v < VPL; ++v)
+                    if (ok[v]) st<VEC>(dq + r * H + cb[v], q[v]);
+            }
 #pragma unroll
             for (int k = 0; k < HDP; ++k) {
                 if (k < HD) {
@@ -711,7 +718,9 @@ DCC_API int64_t dcc_mlp_workspace_floats(int32_t H, int32_t HD) {
     const int hdp = pad_hd(HD);
     if (hdp < 0) return 0;
     const int64_t a = (int64_t)kReluLnBlocks * kWavesPerBlock * (3 + kAMax) * H;
-    const int64_t b = HD > 0 ? (int64_t)kL1Blocks * kWavesPerBlock * (hdp + 4) * H : 0;
+    int64_t b = HD > 0 ? (int64_t)kL1Blocks * kWavesPerBlock * (hdp + 4) * H : 0;
+    const int64_t b2 = HD > 0 ? (int64_t)kL1Blocks * 2 * kWavesPerBlock * 4 * H : 0;
+    if (b2 > b) b = b2;
     return a > b ? a : b;
 }
 
@@ -798,9 +807,9 @@ DCC_API int dcc_actor_l1_fwd(const float* head, const float* G, const double* st
 
 DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
                              const float* c, const float* gamma, const float* dh, float eps_in, float eps_ln, int32_t D,
-                             float* dG, float* dWh, float* ds, float* dc, float* dgamma, float* dbeta, float* workspace,
-                             int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
-    if (!head || !G || !Wh || !s || !c || !gamma || !dh || !dG || !dWh || !ds || !dc || !dgamma || !dbeta ||
+                             float* dG, float* dWh, float* dq, float* ds, float* dc, float* dgamma, float* dbeta,
+                             float* workspace, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
+    if (!head || !G || !Wh || !s || !c || !gamma || !dh || !dG || (!dWh && !dq) || !ds || !dc || !dgamma || !dbeta ||
         !workspace || n < 1 || N < 1 || D < 1)
         return kEINVAL;
     Shape sh;
@@ -813,16 +822,25 @@ DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* st
         return kEINVAL;
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
     const int grid = (int)waves_for(n, kL1Blocks);
-    switch (hdp) {
-        case 8: launch_l1_bwd<8>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
-        case 16: launch_l1_bwd<16>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
-        case 24: launch_l1_bwd<24>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
-        default: launch_l1_bwd<40>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+    int hdp_used = hdp;
+    int grid_used = grid;
+    if (dq) {   // two-kernel variant: light registers -> full occupancy, so use the larger grid too
+        if (sh.vec == 4 && !aligned16(dq)) return kEINVAL;
+        grid_used = (int)waves_for(n, kL1Blocks * 2);
+        launch_l1_bwd<0>(sh, grid_used, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H);
+    } else {
+        switch (hdp) {
+            case 8: launch_l1_bwd<8>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+            case 16: launch_l1_bwd<16>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+            case 24: launch_l1_bwd<24>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+            default: launch_l1_bwd<40>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+        }
     }
-    const int P = (hdp + 4) * H;
-    const long long nseg = reduce_stage1(workspace, (long long)grid * kWavesPerBlock, P, P, st_);
+    if (dq) hdp_used = 0;
+    const int P = (hdp_used + 4) * H;
+    const long long nseg = reduce_stage1(workspace, (long long)grid_used * kWavesPerBlock, P, P, st_);
     hipLaunchKernelGGL(l1_reduce_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace, nseg,
-                       (long long)kSegWaves * P, hdp, (int)HD, (int)H, dWh, ds, dc, dgamma, dbeta);
+                       (long long)kSegWaves * P, hdp_used, (int)HD, (int)H, dWh, ds, dc, dgamma, dbeta);
     return hipGetLastError() == hipSuccess ? 0 : kEHIP;
 }
 

@@ -85,7 +85,7 @@ def load_library(path=None):
     L.dcc_mlp_workspace_floats.argtypes = [i32, i32]
     L.dcc_mlp_workspace_floats.restype = i64
     L.dcc_actor_l1_fwd.argtypes = [_vp] * 8 + [f32, f32, i32, _vp, i64, i32, i32, i32, _vp]
-    L.dcc_actor_l1_bwd.argtypes = [_vp] * 8 + [f32, f32, i32] + [_vp] * 7 + [i64, i32, i32, i32, _vp]
+    L.dcc_actor_l1_bwd.argtypes = [_vp] * 8 + [f32, f32, i32] + [_vp] * 8 + [i64, i32, i32, i32, _vp]
     if L.dcc_abi_version() != 2:
         raise DccError("libdcc_hip.so ABI version %d != 2" % L.dcc_abi_version())
     _lib = L
@@ -409,17 +409,33 @@ def actor_l1_fwd(head, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, D):
     return h
 
 
-def actor_l1_bwd(head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, D):
+def actor_l1_bwd(head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, D, two_kernel=None):
+    """-> dG, dWh, ds, dc, dgamma, dbeta.  two_kernel (default: for >= 65536 rows): the HIP kernel stores q = rstd_in * dz and
+    dWh = q^T head is issued as a split-K batched GEMM (see include/dcc_mlp.h)."""
     n, N, HD = head.shape
     H = G.shape[1]
     L = load_library()
     dev = head.device
+    R = n * N
+    if two_kernel is None:
+        two_kernel = R >= 65536
     dG = torch.empty_like(G)
-    dWh = torch.empty((H, HD), dtype=torch.float32, device=dev)
     vecs = torch.empty((4, H), dtype=torch.float32, device=dev)     # ds, dc, dgamma, dbeta
     ws = torch.empty(L.dcc_mlp_workspace_floats(H, HD), dtype=torch.float32, device=dev)
+    dq = torch.empty((R, H), dtype=torch.float32, device=dev) if two_kernel else None
+    dWh = None if two_kernel else torch.empty((H, HD), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _check(L.dcc_actor_l1_bwd(_ptr(head), _ptr(G), _ptr(stats), _ptr(Wh), _ptr(s), _ptr(c), _ptr(gamma),
-                                  _ptr(_f32c(dh, "dh")), eps_in, eps_ln, D, _ptr(dG), _ptr(dWh), _ptr(vecs[0]), _ptr(vecs[1]),
-                                  _ptr(vecs[2]), _ptr(vecs[3]), _ptr(ws), n, N, HD, H, _stream()), "dcc_actor_l1_bwd")
+                                  _ptr(_f32c(dh, "dh")), eps_in, eps_ln, D, _ptr(dG), _ptr(dWh), _ptr(dq), _ptr(vecs[0]),
+                                  _ptr(vecs[1]), _ptr(vecs[2]), _ptr(vecs[3]), _ptr(ws), n, N, HD, H, _stream()),
+               "dcc_actor_l1_bwd")
+    if two_kernel:
+        S = 128
+        while S > 1 and R % S:
+            S //= 2
+        hf = head.view(R, HD)
+        if S > 1:
+            dWh = torch.bmm(dq.view(S, R // S, H).transpose(1, 2), hf.view(S, R // S, HD)).sum(0)
+        else:
+            dWh = dq.t() @ hf
     return dG, dWh, vecs[0], vecs[1], vecs[2], vecs[3]

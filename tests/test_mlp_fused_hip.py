@@ -203,3 +203,25 @@ def test_split_k_linear_matches_plain(R, K, H):
     assert torch.equal(y1, y2)
     _close(x1.grad, x2.grad, "dx", rtol=1e-5, atol=1e-6)
     _close(W1.grad, W2.grad, "dW", rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,N,H", [(517, 8, 256), (33, 4, 64), (8200, 8, 64)])
+def test_actor_l1_backward_one_and_two_kernel_variants_agree(n, N, H):
+    """dq == NULL (dWh accumulated in registers) and dq != NULL (q stored, dWh = q^T head as a batched GEMM) are the
+    same gradients; the second is what long batches use."""
+    import dcc_hip
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(n + N + H)
+    HD = 4 + 2 * (N - 1)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    head, G = rnd(n, N, HD), rnd(n, H)
+    stats = torch.stack([rnd(n, N).double() * 0.1 + 1.0, torch.rand(n, N, device=dev, generator=g).double() * 300 + 600], -1).contiguous()
+    Wh, s, c = rnd(H, HD) * 0.2, rnd(H), rnd(H)
+    gamma, dh = torch.rand(H, device=dev, generator=g) + 0.5, rnd(n * N, H)
+    a = dcc_hip.actor_l1_bwd(head, G, stats, Wh, s, c, gamma, dh, 1e-5, 1e-5, 338, two_kernel=False)
+    b = dcc_hip.actor_l1_bwd(head, G, stats, Wh, s, c, gamma, dh, 1e-5, 1e-5, 338, two_kernel=True)
+    for name, x, y in zip(("dG", "dWh", "ds", "dc", "dgamma", "dbeta"), a, b):
+        _close(y, x, name, rtol=1e-4, atol=1e-5)
+    assert torch.equal(a[0], b[0])       # dG takes the same in-register path in both
+    b2 = dcc_hip.actor_l1_bwd(head, G, stats, Wh, s, c, gamma, dh, 1e-5, 1e-5, 338, two_kernel=True)
+    assert all(torch.equal(x, y) for x, y in zip(b, b2))
