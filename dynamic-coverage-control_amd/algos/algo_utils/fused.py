@@ -145,3 +145,44 @@ def actor_l1(head, G, stats, Wh, s, c, ln, eps_in, D):
     else:
         z = z + c
     return ln(F.relu(z.reshape(n * N, -1)))   # (the block's own Linear bias is already folded into c)
+
+
+class _PolicyLoss(torch.autograd.Function):
+    """PPO-clip surrogate + Gaussian entropy from the action mean in one HIP pass (include/dcc_mlp.h:
+    dcc_ppo_policy_loss); returns (policy_loss, dist_entropy, mean ratio)."""
+
+    @staticmethod
+    def forward(ctx, mean, logstd, actions, old_logp, adv, active, clip, use_active):
+        import dcc_hip
+        R, A = mean.shape
+        act = active.reshape(R).contiguous() if (use_active and active is not None) else None
+        dmean_raw, sums = dcc_hip.ppo_policy_loss(mean.contiguous(), logstd.contiguous(), actions.contiguous(),
+                                                  old_logp.contiguous(), adv.reshape(R).contiguous(), act, clip)
+        denom = sums[1] if act is not None else torch.full((), float(R), device=mean.device)
+        ctx.save_for_backward(dmean_raw, sums, denom)
+        ctx.A, ctx.masked = A, act is not None
+        policy_loss = -sums[0] / denom
+        ent = (logstd + (0.5 + LOG_SQRT_2PI)).sum()          # sum over the action dims of the per-dim entropy
+        if act is None:
+            ent = ent / A                                      # `ent.mean()` averages over the dims as well (act.py:177-179)
+        return policy_loss, ent, sums[2] / (R * old_logp.shape[1])
+
+    @staticmethod
+    def backward(ctx, g_pl, g_ent, g_ratio):
+        dmean_raw, sums, denom = ctx.saved_tensors
+        scale = g_pl / denom
+        dlogstd = sums[4:4 + ctx.A] * scale + g_ent * (1.0 if ctx.masked else 1.0 / ctx.A)
+        return dmean_raw * scale, dlogstd, None, None, None, None, None, None
+
+
+LOG_SQRT_2PI = 0.91893853320467274178
+
+
+def policy_loss_usable(mean, old_logp):
+    return (ENABLED and mean.is_cuda and mean.dtype == torch.float32 and mean.dim() == 2 and mean.shape[1] <= HEAD_MAX_OUT
+            and old_logp.shape[1] <= HEAD_MAX_OUT and not torch.is_autocast_enabled())
+
+
+def policy_loss(mean, logstd, actions, old_logp, adv, active, clip, use_active):
+    """(policy_loss, dist_entropy, ratio_mean) of mappo.py:150-160 / act.py:165-179 from the Gaussian mean."""
+    return _PolicyLoss.apply(mean, logstd, actions, old_logp, adv, active, float(clip), bool(use_active))

@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 
 import utils.pytorch_utils as ptu
+from algos.algo_utils import fused
 from algos.r_actor_critic import R_Actor, R_Critic
 from utils.util import get_gard_norm, huber_loss, mse_loss, update_linear_schedule
 from utils.valuenorm import ValueNorm
@@ -177,24 +178,36 @@ class MAPPOTrainer:
             obs_batch, share_obs_batch = t(obs_batch), t(share_obs_batch)
         n_rows = actions_batch.shape[0]
 
+        actor = self.policy.actor
+        fused_loss = (not self.amp_bf16 and ptu.device.type == "cuda" and available_actions_batch is None
+                      and fused.policy_loss_usable(actions_batch, old_logp))
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp_bf16):
-            action_log_probs, dist_entropy = self.policy.actor.evaluate_actions(
-                obs_batch, rnn_states_batch, actions_batch, masks_batch, available_actions_batch, active_masks_batch,
-                prenormalized=prenormalized)
+            if fused_loss:      # surrogate, entropy and their gradients in one HIP pass over [B, A] (dcc_ppo_policy_loss)
+                mean = actor._mean(obs_batch, prenormalized)
+            else:
+                action_log_probs, dist_entropy = actor.evaluate_actions(
+                    obs_batch, rnn_states_batch, actions_batch, masks_batch, available_actions_batch, active_masks_batch,
+                    prenormalized=prenormalized)
             values = self.policy.critic(share_obs_batch, prenormalized=prenormalized)[0]
-        action_log_probs, dist_entropy, values = action_log_probs.float(), dist_entropy.float(), values.float()
+        values = values.float()
         if values.shape[0] != n_rows:
             n_rep = n_rows // values.shape[0]
             values = values.unsqueeze(1).expand(-1, n_rep, -1).reshape(-1, 1)
 
-        imp_weights = torch.exp(action_log_probs - old_logp)   # [B, A] when old_logp keeps the reference's [.,2] layout
-        surr1 = imp_weights * adv_targ
-        surr2 = torch.clamp(imp_weights, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_targ
-        surr = torch.sum(torch.min(surr1, surr2), dim=-1, keepdim=True)
-        if self._use_policy_active_masks:
-            policy_loss = (-surr * active_masks_batch).sum() / active_masks_batch.sum()
+        if fused_loss:
+            policy_loss, dist_entropy, imp_weights = fused.policy_loss(
+                mean, actor.act.action_out.logstd._bias.view(-1), actions_batch, old_logp, adv_targ, active_masks_batch,
+                self.clip_param, self._use_policy_active_masks)
         else:
-            policy_loss = -surr.mean()
+            action_log_probs, dist_entropy = action_log_probs.float(), dist_entropy.float()
+            imp_weights = torch.exp(action_log_probs - old_logp)   # [B, A] when old_logp keeps the reference's [.,2] layout
+            surr1 = imp_weights * adv_targ
+            surr2 = torch.clamp(imp_weights, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_targ
+            surr = torch.sum(torch.min(surr1, surr2), dim=-1, keepdim=True)
+            if self._use_policy_active_masks:
+                policy_loss = (-surr * active_masks_batch).sum() / active_masks_batch.sum()
+            else:
+                policy_loss = -surr.mean()
         value_loss = self.cal_value_loss(values, value_preds_batch, return_batch, active_masks_batch, update_norm)
         return policy_loss, dist_entropy, value_loss, imp_weights
 

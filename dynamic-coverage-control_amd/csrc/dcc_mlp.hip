@@ -387,6 +387,77 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_k(const float* __restr
     out[p] = (s0 + s1) + (s2 + s3);
 }
 
+// ---- PPO-clip policy surrogate of a diagonal Gaussian, forward and gradient in one pass ----------------------------
+// One thread per row.  logp = sum_d [-(a_d-mu_d)^2 / (2 sigma_d^2) - log sigma_d - log sqrt(2 pi)];  for each of the K
+// stored old-log-prob columns (the reference keeps K = A identical columns) ratio = exp(logp - old),
+// surr = min(ratio adv, clamp(ratio, 1-eps, 1+eps) adv) summed over the columns.  Gradients follow PyTorch's rules
+// (minimum splits a tie evenly, clamp passes the gradient inside the closed range).  Outputs: dmean_raw =
+// d(-sum_r act_r surr_r)/d mean, per-block partial sums [S_surr, S_act, S_ratio, 0, dlogstd_raw[0..3]].
+constexpr int kPpoP = 8;
+__global__ __launch_bounds__(kBlock) void ppo_policy_loss_k(const float* __restrict__ mean, const float* __restrict__ logstd,
+                                                            const float* __restrict__ actions,
+                                                            const float* __restrict__ old_logp,
+                                                            const float* __restrict__ adv, const float* __restrict__ active,
+                                                            float clip, float* __restrict__ dmean, float* __restrict__ ws,
+                                                            long long R, int A, int K) {
+    __shared__ float red[kWavesPerBlock][kPpoP];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float ls[kAMax], inv_var[kAMax];
+    float logc = 0.f;
+#pragma unroll
+    for (int d = 0; d < kAMax; ++d) {
+        ls[d] = d < A ? logstd[d] : 0.f;
+        inv_var[d] = __expf(-2.f * ls[d]);
+        if (d < A) logc += ls[d] + 0.91893853320467274178f;   // log sigma + log sqrt(2 pi)
+    }
+    const float lo = 1.f - clip, hi = 1.f + clip;
+    float acc[kPpoP] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long long r = (long long)blockIdx.x * kBlock + threadIdx.x; r < R; r += (long long)gridDim.x * kBlock) {
+        float dev[kAMax], q = 0.f;
+#pragma unroll
+        for (int d = 0; d < kAMax; ++d) {
+            dev[d] = 0.f;
+            if (d < A) { dev[d] = actions[r * A + d] - mean[r * A + d]; q += dev[d] * dev[d] * inv_var[d]; }
+        }
+        const float logp = -0.5f * q - logc;
+        const float a = adv[r];
+        const float act = active ? active[r] : 1.f;
+        float surr = 0.f, coef = 0.f;
+#pragma unroll
+        for (int k = 0; k < kAMax; ++k)
+            if (k < K) {
+                const float ratio = expf(logp - old_logp[r * K + k]);
+                const float s1 = ratio * a, s2 = fminf(fmaxf(ratio, lo), hi) * a;
+                const float g1 = ratio * a;                                   // d s1 / d logp
+                const float g2 = (ratio >= lo && ratio <= hi) ? ratio * a : 0.f;   // d s2 / d logp
+                surr += fminf(s1, s2);
+                coef += s1 < s2 ? g1 : (s1 > s2 ? g2 : 0.5f * (g1 + g2));
+                acc[2] += ratio;
+            }
+        acc[0] += surr * act;
+        acc[1] += act;
+        const float w = -coef * act;          // d(-act surr)/d logp
+#pragma unroll
+        for (int d = 0; d < kAMax; ++d)
+            if (d < A) {
+                dmean[r * A + d] = w * dev[d] * inv_var[d];
+                acc[4 + d] += w * (dev[d] * dev[d] * inv_var[d] - 1.f);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < kPpoP; ++i) {
+        const float t = wave_sum(acc[i]);
+        if (lane == 0) red[wid][i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < kPpoP) {
+        float t = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < kWavesPerBlock; ++w2) t += red[w2][threadIdx.x];
+        ws[(long long)blockIdx.x * kPpoP + threadIdx.x] = t;
+    }
+}
+
 // ---- actor first block from compact features -------------------------------------------------------------------
 // z[r,c] = rstd_in[r] * (sum_k head[r,k] Wh[c,k] + G[e,c] - mean_in[r] s[c]) + cb[c];   h = LayerNorm(ReLU(z))
 // One wave per env: G[e] is loaded once for its N agent rows and (backward) dG[e] is summed in registers.
@@ -785,6 +856,21 @@ DCC_API int dcc_relu_ln_head_bwd(const float* z, const float* bias, const float*
     const long long nseg = reduce_stage1(workspace, (long long)grid * kWavesPerBlock, P, stride, st_);
     hipLaunchKernelGGL(reduce_partials_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace, nseg, P,
                        kSegWaves * stride, dparams);
+    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+}
+
+DCC_API int dcc_ppo_policy_loss(const float* mean, const float* logstd, const float* actions, const float* old_logp,
+                                const float* adv, const float* active, float clip, float* dmean, float* sums,
+                                float* workspace, int64_t R, int32_t A, int32_t K, void* stream) {
+    if (!mean || !logstd || !actions || !old_logp || !adv || !dmean || !sums || !workspace || R < 1) return kEINVAL;
+    if (A < 1 || A > kAMax || K < 1 || K > kAMax) return kEUNSUPPORTED;
+    hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
+    long long blocks = (R + kBlock - 1) / kBlock;
+    if (blocks > kReluLnBlocks * 2) blocks = kReluLnBlocks * 2;
+    hipLaunchKernelGGL(ppo_policy_loss_k, dim3((unsigned)blocks), dim3(kBlock), 0, st_, mean, logstd, actions, old_logp, adv,
+                       active, clip, dmean, workspace, (long long)R, (int)A, (int)K);
+    const long long nseg = reduce_stage1(workspace, blocks, kPpoP, kPpoP, st_);
+    hipLaunchKernelGGL(reduce_partials_k, dim3(1), dim3(kBlock), 0, st_, workspace, nseg, kPpoP, kSegWaves * kPpoP, sums);
     return hipGetLastError() == hipSuccess ? 0 : kEHIP;
 }
 

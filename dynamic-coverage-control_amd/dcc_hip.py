@@ -43,7 +43,7 @@ class EnvOut(ctypes.Structure):
 EXPORTS = ["dcc_obs_expand", "dcc_gae_compute", "dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
            "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout", "dcc_env_get_state",
            "dcc_env_set_state", "dcc_env_bytes_per_step", "dcc_obs_features",
-           "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_relu_ln_head_fwd", "dcc_relu_ln_head_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd"]
+           "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_relu_ln_head_fwd", "dcc_relu_ln_head_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd", "dcc_ppo_policy_loss"]
 
 _lib = None
 
@@ -82,6 +82,7 @@ def load_library(path=None):
     L.dcc_relu_ln_bwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, _vp, _vp, i64, i32, _vp]
     L.dcc_relu_ln_head_fwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, _vp, _vp, i64, i32, i32, _vp]
     L.dcc_relu_ln_head_bwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, _vp, _vp, _vp, _vp, i64, i32, i32, _vp]
+    L.dcc_ppo_policy_loss.argtypes = [_vp] * 6 + [f32, _vp, _vp, _vp, i64, i32, i32, _vp]
     L.dcc_mlp_workspace_floats.argtypes = [i32, i32]
     L.dcc_mlp_workspace_floats.restype = i64
     L.dcc_actor_l1_fwd.argtypes = [_vp] * 8 + [f32, f32, i32, _vp, i64, i32, i32, i32, _vp]
@@ -392,6 +393,22 @@ def relu_ln_head_bwd(z, bias, gamma, beta, eps, Wo, dy):
                                       eps, _ptr(_f32c(Wo, "Wo")), _ptr(_f32c(dy, "dy")), _ptr(dz), _ptr(dp), _ptr(ws), R, H, A,
                                       _stream()), "dcc_relu_ln_head_bwd")
     return dz, dp[0], dp[1], dp[2], dp[3:]
+
+
+def ppo_policy_loss(mean, logstd, actions, old_logp, adv, active, clip):
+    """-> dmean_raw [R,A], sums [8] (see include/dcc_mlp.h: dcc_ppo_policy_loss)."""
+    R, A = mean.shape
+    K = old_logp.shape[1]
+    dev = mean.device
+    dmean = torch.empty_like(_f32c(mean, "mean"))
+    sums = torch.empty(8, dtype=torch.float32, device=dev)
+    ws = torch.empty(8 * 2048, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load_library().dcc_ppo_policy_loss(_ptr(mean), _ptr(_f32c(logstd, "logstd")), _ptr(_f32c(actions, "actions")),
+                                                  _ptr(_f32c(old_logp, "old_logp")), _ptr(_f32c(adv, "adv")),
+                                                  _ptr(None if active is None else _f32c(active, "active")), clip, _ptr(dmean),
+                                                  _ptr(sums), _ptr(ws), R, A, K, _stream()), "dcc_ppo_policy_loss")
+    return dmean, sums
 
 
 def actor_l1_fwd(head, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, D):

@@ -66,6 +66,22 @@ DCC_API int dcc_relu_ln_head_bwd(const float* z, const float* bias, const float*
                                  int32_t H, int32_t A, void* stream);
 
 /*
+ * PPO-clip policy surrogate of a diagonal Gaussian policy, value and gradient in one pass over the batch
+ * (algos/mappo.py:150-160 + Normal.log_prob via algo_utils/act.py:165-172 and distributions.py:72-81):
+ *   logp_r = sum_d Normal(mean[r,d], exp(logstd[d])).log_prob(actions[r,d]);  ratio[r,k] = exp(logp_r - old_logp[r,k])
+ *   surr_r = sum_k min(ratio adv_r, clamp(ratio, 1-clip, 1+clip) adv_r)
+ * mean, actions [R,A]; logstd [A]; old_logp [R,K] (the reference stores K = A identical columns);
+ * adv [R]; active [R] or NULL (= all ones).  A, K <= 4.  Outputs:
+ *   dmean [R,A]  = d( -sum_r active_r surr_r ) / d mean        (the caller scales by 1 / sum active, or 1 / R)
+ *   sums  [8]    = { sum_r active_r surr_r, sum_r active_r, sum_{r,k} ratio, 0, d(-sum active surr)/d logstd[0..3] }
+ * workspace: >= 8 * 2048 floats.  Gradient conventions are PyTorch's (minimum splits ties evenly, clamp passes the
+ * gradient on the closed interval), so the result equals autograd on the unfused expression.
+ */
+DCC_API int dcc_ppo_policy_loss(const float* mean, const float* logstd, const float* actions, const float* old_logp,
+                                const float* adv, const float* active, float clip, float* dmean, float* sums,
+                                float* workspace, int64_t R, int32_t A, int32_t K, void* stream);
+
+/*
  * Actor first block from compact features of n env states with N agents each (rows r = e*N + i):
  *   head  [n,N,HD] f32, HD = 4 + 2(N-1)      dcc_obs_features
  *   G     [n,H]    f32                       per-env term  poi_feat . [We;Wd]^T + const   (shared by the N agents)

@@ -225,3 +225,50 @@ def test_actor_l1_backward_one_and_two_kernel_variants_agree(n, N, H):
     assert torch.equal(a[0], b[0])       # dG takes the same in-register path in both
     b2 = dcc_hip.actor_l1_bwd(head, G, stats, Wh, s, c, gamma, dh, 1e-5, 1e-5, 338, two_kernel=True)
     assert all(torch.equal(x, y) for x, y in zip(b, b2))
+
+
+@pytest.mark.parametrize("R,A,K,masked", [(100003, 2, 2, True), (5000, 2, 2, False), (777, 3, 1, True), (64, 1, 4, False)])
+def test_fused_policy_loss_matches_autograd(R, A, K, masked):
+    """dcc_ppo_policy_loss == autograd on the reference's expression (mappo.py:150-160, act.py:165-179): loss, entropy,
+    mean ratio, d/d mean and d/d logstd; clipped and unclipped ratios on both sides, partially inactive rows."""
+    from algos.algo_utils import fused
+    from algos.algo_utils.distributions import FixedNormal
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(R + A)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    mean0 = rnd(R, A) * 0.5
+    logstd0 = rnd(A) * 0.2
+    actions = mean0 + rnd(R, A) * logstd0.exp()
+    adv = rnd(R, 1)
+    active = (torch.rand(R, 1, device=dev, generator=g) > 0.2).float()
+    with torch.no_grad():       # old log-probs: the current ones perturbed so that some ratios leave [0.8, 1.2]
+        lp = FixedNormal(mean0, logstd0.exp().expand(R, A), validate_args=False).log_probs(actions)
+        old = (lp + rnd(R, 1) * 0.15).expand(R, K).contiguous()
+    clip, coef = 0.2, 0.01
+
+    def run(use_fused):
+        mean, logstd = mean0.clone().requires_grad_(True), logstd0.clone().requires_grad_(True)
+        if use_fused:
+            pl, ent, ratio = fused.policy_loss(mean, logstd, actions, old, adv, active, clip, masked)
+        else:
+            dist = FixedNormal(mean, logstd.exp().view(1, A).expand(R, A), validate_args=False)
+            logp = dist.log_probs(actions)
+            imp = torch.exp(logp - old)
+            surr = torch.min(imp * adv, torch.clamp(imp, 1 - clip, 1 + clip) * adv).sum(-1, keepdim=True)
+            e = dist.entropy()
+            if masked:
+                pl = (-surr * active).sum() / active.sum()
+                ent = (e * active).sum() / active.sum()
+            else:
+                pl, ent = -surr.mean(), e.mean()
+            ratio = imp.mean()
+        (pl - ent * coef).backward()
+        return pl.detach(), ent.detach(), ratio.detach(), mean.grad.clone(), logstd.grad.clone()
+
+    f, t = run(True), run(False)
+    frac_clipped = float(((torch.exp(lp - old[:, :1]) - 1).abs() > clip).float().mean())
+    assert 0.05 < frac_clipped < 0.95
+    for name, a, b in zip(("policy_loss", "entropy", "ratio", "dmean", "dlogstd"), f, t):
+        _close(a, b, name, rtol=2e-5, atol=2e-6)
+    f2 = run(True)
+    assert all(torch.equal(a, b) for a, b in zip(f, f2))
