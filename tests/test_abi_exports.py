@@ -78,3 +78,25 @@ def test_bytes_per_step_matches_survey_figures():
     assert dcc_hip.bytes_per_step(16, 256) == 87563
     assert dcc_hip.bytes_per_step(32, 1024) == 676363
     assert dcc_hip.bytes_per_step(8, 64, with_actions=False) == 11851 - 64
+
+
+def test_mlp_entry_points_validate_before_touching_the_device():
+    """include/dcc_mlp.h: shape support query and argument validation run on the host (no GPU needed here)."""
+    import dcc_hip
+    L = dcc_hip.load_library()
+    assert L.dcc_mlp_workspace_floats(256, 18) >= L.dcc_mlp_workspace_floats(256, 0) > 0
+    assert L.dcc_mlp_workspace_floats(64, 10) > 0 and L.dcc_mlp_workspace_floats(512, 0) > 0
+    for H, HD in ((1000, 0), (130, 0), (0, 0), (256, 41), (516, 0)):
+        assert L.dcc_mlp_workspace_floats(H, HD) == 0, (H, HD)
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert L.dcc_relu_ln_fwd(None, None, p, p, 1e-5, p, 4, 8, None) == -1            # null z
+    assert L.dcc_relu_ln_fwd(p, None, p, p, 1e-5, p, 4, 1000, None) == -4            # unsupported width
+    assert L.dcc_relu_ln_fwd(p, None, p, p, 1e-5, p, 0, 8, None) == 0                # empty batch: nothing to launch
+    assert L.dcc_relu_ln_bwd(p, None, p, p, 1e-5, p, p, None, 4, 8, None) == -1      # no workspace
+    assert L.dcc_relu_ln_head_fwd(p, None, p, p, 1e-5, p, None, p, 4, 8, 5, None) == -4    # head wider than 4
+    assert L.dcc_relu_ln_head_bwd(p, None, p, p, 1e-5, p, p, p, p, None, 4, 8, 2, None) == -1
+    assert L.dcc_actor_l1_fwd(p, p, None, p, p, p, p, p, 1e-5, 1e-5, 90, p, 1, 4, 70, 8, None) == -4   # head width > 64
+    assert L.dcc_actor_l1_bwd(p, p, None, p, p, p, p, p, 1e-5, 1e-5, 90, p, None, None, p, p, p, p, p, 1, 4, 10, 8, None) == -1
+    assert L.dcc_ppo_policy_loss(p, p, p, p, p, None, 0.2, p, p, p, 16, 5, 2, None) == -4   # more than 4 action dims
+    assert L.dcc_ppo_policy_loss(p, p, p, p, p, None, 0.2, None, p, p, 16, 2, 2, None) == -1

@@ -304,3 +304,25 @@ def test_structured_input_with_shapes_outside_the_fused_variants():
         np.testing.assert_allclose(v_s.cpu().numpy(), v_d.cpu().numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(a_s.cpu().numpy(), a_d.cpu().numpy(), rtol=1e-4, atol=1e-5)
     ptu.set_gpu_mode(False)
+
+
+def test_structured_learner_full_train_loop_with_eval_envs(tmp_path):
+    """Learner.train() end to end on the fast path: structured input, hipGraph rollouts for the train AND the eval
+    buffer, LR decay, periodic eval rollout, checkpoint written and reloadable."""
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    cfg = _cfg(n_rollout_threads=64, n_eval_rollout_threads=16, num_agents=4, num_pois=20, max_ep_len=15, n_iters=3,
+               ppo_epoch=2, algo_hidden_size=64, save_model=True, save_interval=3, eval_interval=1, log_interval=1,
+               main_save_path=str(tmp_path), structured_input=True)
+    lr = Learner(cfg)
+    lr.train()
+    assert lr.rl_buffer.structured and lr.test_buffer.structured and len(lr._graphs) == 2
+    assert os.path.exists(os.path.join(lr.output_path, "models_3.pt", "agent.pkl"))
+    lr2 = Learner(_cfg(**dict(vars(cfg), save_model=False, seed=7)))
+    lr2.load_checkpoint(os.path.join(lr.output_path, "models_3.pt", "resume.pt"))
+    for (k, a), (_, b) in zip(lr.policy.actor.state_dict().items(), lr2.policy.actor.state_dict().items()):
+        assert torch.equal(a, b), k
+    res = lr2.evaluate(steps=10)
+    assert 0.0 <= res["coverage_rate"] <= 1.0
+    ptu.set_gpu_mode(False)
