@@ -65,19 +65,69 @@ def features_from_obs(obs, layout):
     return dict(head=head, poi_feat=poi_feat, stats=torch.stack([mean, m2], dim=-1))
 
 
-def _folded(base):
+class _FoldedWeights(torch.autograd.Function):
+    """All weight-side quantities of the structured layer in one autograd node (the slicing / summing of the
+    parameters written with plain torch ops costs >100 tiny kernel launches per network and epoch through autograd;
+    here ~15 forward and ~15 backward).  Nb = 1 (actor: W [H, D]) or N (critic: W [H, N*D], per-agent blocks).
+
+        wf = W * gamma,  c = b + W beta,  s = rowsum(wf)
+        w_h [H, Nb*HD]  head columns of every block, the pos_i columns minus sum_j wf_xy,j
+        w_ed [H, 2M]    energy and done columns, summed over the blocks
+        const [H]       sum_j poi_j wf_xy,j + m_energy sum_j wf_m,j   (over all blocks)
+    """
+
+    @staticmethod
+    def forward(ctx, W, b, gamma, beta, poi, m_energy, Nb, HD, M):
+        H = W.shape[0]
+        D = HD + 5 * M
+        wf = W * gamma if gamma is not None else W
+        c = b + W @ beta if beta is not None else b.clone()
+        s = wf.sum(1)
+        w3 = wf.view(H, Nb, D)
+        P = w3[:, :, HD:].reshape(H, Nb, M, 5)
+        w_h = w3[:, :, :HD].clone()
+        w_h[:, :, 2:4] -= P[..., 0:2].sum(2)
+        w_ed = torch.cat([P[..., 2].sum(1), P[..., 4].sum(1)], dim=1)
+        const = (P[..., 0:2] * poi).sum((1, 2, 3)) + m_energy * P[..., 3].sum((1, 2))
+        ctx.save_for_backward(W, gamma, beta, poi)
+        ctx.dims = (Nb, HD, M, float(m_energy))
+        return w_h.reshape(H, Nb * HD), w_ed, const, s, c
+
+    @staticmethod
+    def backward(ctx, g_wh, g_wed, g_const, g_s, g_c):
+        W, gamma, beta, poi = ctx.saved_tensors
+        Nb, HD, M, m_energy = ctx.dims
+        H = W.shape[0]
+        g_wh3 = g_wh.reshape(H, Nb, HD)
+        gP = torch.empty(H, Nb, M, 5, dtype=W.dtype, device=W.device)
+        gP[..., 0:2] = g_const.view(H, 1, 1, 1) * poi - g_wh3[:, :, 2:4].unsqueeze(2)
+        gP[..., 2] = g_wed[:, :M].unsqueeze(1)
+        gP[..., 3] = (m_energy * g_const).view(H, 1, 1)
+        gP[..., 4] = g_wed[:, M:].unsqueeze(1)
+        g_wf = torch.cat([g_wh3, gP.view(H, Nb, 5 * M)], dim=2).view(H, -1) + g_s.unsqueeze(1)
+        if gamma is not None:
+            g_W = g_wf * gamma
+            g_gamma = (g_wf * W).sum(0)
+        else:
+            g_W, g_gamma = g_wf, None
+        g_beta = None
+        if beta is not None:
+            g_W = g_W + g_c.unsqueeze(1) * beta
+            g_beta = g_c @ W
+        return g_W, g_c, g_gamma, g_beta, None, None, None, None, None
+
+
+def folded_weights(base, layout, Nb):
+    """(w_h, w_ed, const, s, c, eps) of the structured first layer of `base` (see _FoldedWeights)."""
     lin = base.mlp.fc1[0]
     if base._use_feature_normalization:
         ln = base.feature_norm
-        return lin.weight * ln.weight.unsqueeze(0), lin.bias + lin.weight @ ln.bias, ln.eps
-    return lin.weight, lin.bias, None
-
-
-def _split(wf, layout):
-    """wf [..., D] -> head [..., HD], xy [..., M, 2], e/m/d [..., M]."""
-    HD, M = layout.HD, layout.M
-    poi = wf[..., HD:].reshape(wf.shape[:-1] + (M, 5))
-    return wf[..., :HD], poi[..., 0:2], poi[..., 2], poi[..., 3], poi[..., 4]
+        gamma, beta, eps = ln.weight, ln.bias, ln.eps
+    else:
+        gamma = beta = eps = None
+    out = _FoldedWeights.apply(lin.weight, lin.bias, gamma, beta, layout.poi(lin.weight), layout.m_energy, Nb, layout.HD,
+                               layout.M)
+    return out + (eps,)
 
 
 def _tail(blk, z, bias=None):
@@ -103,20 +153,17 @@ def actor_trunk(base, layout, feats, head=None):
     """MLPBase(obs rows) for the n*N agent rows described by feats -> [n*N, H] (or head(.) -> [n*N, A])."""
     head_f, poi_feat, stats = feats["head"], feats["poi_feat"], feats["stats"]
     n, N, HD = head_f.shape
-    wf, c, eps = _folded(base)                                   # [H, D], [H]
-    w_head, w_xy, w_e, w_m, w_d = _split(wf, layout)
-    w_h = torch.cat([w_head[:, :2], w_head[:, 2:4] - w_xy.sum(1), w_head[:, 4:]], dim=1)       # pos_i also shifts every PoI
-    const = (w_xy * layout.poi(wf)).sum((1, 2)) + layout.m_energy * w_m.sum(1)        # [H]
-    g = (fused.linear_w(poi_feat, torch.cat([w_e, w_d], dim=1)) + const).to(wf.dtype)          # [n, H] shared by the agents
+    w_h, w_ed, const, s_w, c, eps = folded_weights(base, layout, 1)      # [H,HD], [H,2M], [H], [H], [H]
+    g = fused.linear_w(poi_feat, w_ed) + const                          # [n, H] shared by the agents of an env
     blk = base.mlp.fc1
     if isinstance(blk[1], nn.ReLU):   # one fused pass: the pre-activation never reaches memory (include/dcc_mlp.h)
-        h = fused.actor_l1(head_f, g, stats if eps is not None else None, w_h, wf.sum(1), c, blk[2], eps, layout.D)
+        h = fused.actor_l1(head_f, g, stats if eps is not None else None, w_h, s_w, c, blk[2], eps, layout.D)
         return _rest(base, h, head)
     z = F.linear(head_f.reshape(n * N, HD), w_h).view(n, N, -1) + g.unsqueeze(1)
     if eps is not None:
         mean = stats[..., 0]
         rstd = torch.rsqrt(stats[..., 1] / layout.D + eps)
-        z = rstd.to(wf.dtype).unsqueeze(-1) * (z - mean.to(wf.dtype).unsqueeze(-1) * wf.sum(1)) + c
+        z = rstd.to(z.dtype).unsqueeze(-1) * (z - mean.to(z.dtype).unsqueeze(-1) * s_w) + c
     else:
         z = z + c
     return _rest(base, _tail(blk, z.reshape(n * N, -1)), head)
@@ -126,19 +173,14 @@ def critic_trunk(base, layout, feats, head=None):
     """MLPBase(centralised rows = concat of the N agent rows of an env) -> [n, H] (or head(.) -> [n, A])."""
     head_f, poi_feat, stats = feats["head"], feats["poi_feat"], feats["stats"]
     n, N, HD = head_f.shape
-    wf, c, eps = _folded(base)                                   # [H, N*D]
-    H = wf.shape[0]
-    w_head, w_xy, w_e, w_m, w_d = _split(wf.view(H, N, layout.D), layout)      # per-agent blocks
-    w_h = torch.cat([w_head[..., :2], w_head[..., 2:4] - w_xy.sum(2), w_head[..., 4:]], dim=-1).reshape(H, N * HD)
-    const = (w_xy * layout.poi(wf)).sum((1, 2, 3)) + layout.m_energy * w_m.sum((1, 2))
-    z = (fused.linear_w(head_f.reshape(n, N * HD), w_h)
-         + (fused.linear_w(poi_feat, torch.cat([w_e.sum(1), w_d.sum(1)], dim=1)) + const).to(wf.dtype))
+    w_h, w_ed, const, s_w, c, eps = folded_weights(base, layout, N)      # [H,N*HD], [H,2M], [H], [H], [H]
+    z = fused.linear_w(head_f.reshape(n, N * HD), w_h) + (fused.linear_w(poi_feat, w_ed) + const)
     if eps is not None:
         mean_i, m2_i = stats[..., 0], stats[..., 1]                            # [n, N] float64
         mean = mean_i.mean(1, keepdim=True)
         m2 = (m2_i + layout.D * (mean_i - mean) ** 2).sum(1, keepdim=True)     # pooled moments of the N*D-wide row
         rstd = torch.rsqrt(m2 / (N * layout.D) + eps)
-        z = rstd.to(wf.dtype) * (z - mean.to(wf.dtype) * wf.sum(1)) + c
+        z = rstd.to(z.dtype) * (z - mean.to(z.dtype) * s_w) + c
     else:
         z = z + c
     return _rest(base, _tail(base.mlp.fc1, z), head)
