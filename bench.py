@@ -110,7 +110,7 @@ def bench_mappo(args):
                max_ep_len=args.steps_per_launch, ppo_epoch=args.ppo_epoch, save_model=False, n_iters=1,
                comm_force_scale=args.comm_force_scale, r_comm=args.r_comm, amp_bf16=args.amp_bf16,
                use_hip_graph=not args.no_graph, compact_obs=args.compact_obs, update_chunk_steps=args.update_chunk_steps,
-               structured_input=args.structured_input)
+               structured_input=not args.no_structured_input)
     from learner import Learner
     lr = Learner(Namespace(**cfg))
     rank = lr.rank
@@ -148,7 +148,7 @@ def bench_mappo(args):
                                   "steps + HIP GAE + %d full-batch PPO epochs" % (N, args.pois, E, T, args.ppo_epoch),
                       "rollout_s_per_iter": tr / args.iters, "update_s_per_iter": tu / args.iters,
                       "rollout_agent_env_steps_per_sec": world * E * N * T / (tr / args.iters),
-                      "hip_graph_rollout": not args.no_graph, "compact_obs": bool(args.compact_obs), "structured_input": bool(args.structured_input), "update_chunk_steps": args.update_chunk_steps,
+                      "hip_graph_rollout": not args.no_graph, "compact_obs": bool(args.compact_obs), "structured_input": not args.no_structured_input, "update_chunk_steps": args.update_chunk_steps,
                       "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
                       "train_info": {k: float(v) for k, v in tinfo.items()}, "rollout_info": info}}
     if rank == 0:
@@ -183,8 +183,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="--mode mappo: issue the rollout eagerly from Python")
     ap.add_argument("--compact-obs", action="store_true",
                     help="--mode mappo: rollout buffer stores env state, the update regenerates obs per chunk")
-    ap.add_argument("--structured-input", action="store_true",
-                    help="--mode mappo: policy first layers from compact state features; no observation rows")
+    ap.add_argument("--structured-input", action="store_true", help="--mode mappo: (default) first layers from state features")
+    ap.add_argument("--no-structured-input", action="store_true",
+                    help="--mode mappo: dense first layers on the observation rows (reference formulation)")
     ap.add_argument("--update-chunk-steps", type=int, default=0,
                     help="--mode mappo: >0 = chunked full-batch PPO step with gradient accumulation")
     args = ap.parse_args()

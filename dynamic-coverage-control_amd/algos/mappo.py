@@ -297,7 +297,7 @@ class MAPPOTrainer:
         info = {"value_loss": 0.0, "policy_loss": 0.0, "dist_entropy": 0.0, "actor_grad_norm": 0.0,
                 "critic_grad_norm": 0.0, "ratio": 0.0}
         acc = torch.zeros(6, dtype=torch.float64, device=ptu.device)
-        chunked = self.update_chunk_steps > 0 or getattr(buffer, "compact", False)
+        chunked = self.update_chunk_steps > 0 or getattr(buffer, "compact", False) or getattr(buffer, "structured", False)
         if chunked:
             if self.num_mini_batch != 1:
                 raise NotImplementedError("chunked / compact-state updates are full-batch (num_mini_batch: 1)")

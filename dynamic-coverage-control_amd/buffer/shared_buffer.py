@@ -43,26 +43,28 @@ class SharedReplayBuffer(object):
         self._shared_is_view = (S == N * D)
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
         self.compact = bool(compact)
-        if self.compact:
-            if not self._shared_is_view or n_pois is None or expander is None:
-                raise ValueError("compact buffer needs share_obs == concat(obs), n_pois and an expander "
+        # structured input (algos/algo_utils/structured.py): the policy consumes compact features of the state
+        # (dcc_obs_features) in the rollout and in the update.  With compact=False the observation rows are still
+        # stored (buffer.obs / buffer.share_obs stay available, as in the reference); with compact=True they are not.
+        self._featurize = featurizer
+        self.structured = featurizer is not None
+        self.store_state = self.compact or self.structured
+        self._feat_cache = {}
+        if self.store_state:
+            if not self._shared_is_view or n_pois is None or (self.compact and expander is None):
+                raise ValueError("state-storing buffer needs share_obs == concat(obs), n_pois and (compact) an expander "
                                  "(HipCoverageEnv.expand_obs)")
             self._expand = expander
-            # structured input (algos/algo_utils/structured.py): the policy consumes compact features of the state
-            # (dcc_obs_features) and observation rows are never built -- neither in the rollout nor in the update
-            self._featurize = featurizer
-            self.structured = featurizer is not None
-            self._feat_cache = {}
-            self.obs = None
-            self.obs_cur = z(E, N, D)         # observations of the newest slot only
-            self._cur_slot = -1
             self.state_pos = torch.zeros(T + 1, E, N, 2, dtype=torch.float64, device=self.device)
             self.state_vel = torch.zeros(T + 1, E, N, 2, dtype=torch.float64, device=self.device)
             self.state_energy = z(T + 1, E, n_pois)
             self.state_done = torch.zeros(T + 1, E, n_pois, dtype=torch.uint8, device=self.device)
+        if self.compact:
+            self.obs = None
+            self.obs_cur = z(E, N, D)         # observations of the newest slot only
+            self._cur_slot = -1
             self._chunk_obs = None
         else:
-            self.structured = False
             self.obs = z(T + 1, E, N, D)
         self._share_obs = None if (self._shared_is_view or self.compact) else z(T + 1, E, S)
         self.value_preds = z(T + 1, E, N, 1)
@@ -91,15 +93,15 @@ class SharedReplayBuffer(object):
         return self.obs[t]
 
     def state_slot(self, t):
-        """dcc_env_out.state_* destinations of slot t (compact mode), else {}."""
-        if not self.compact:
+        """dcc_env_out.state_* destinations of slot t (compact / structured mode), else {}."""
+        if not self.store_state:
             return {}
         return dict(state_pos=self.state_pos[t], state_vel=self.state_vel[t], state_energy=self.state_energy[t],
                     state_done=self.state_done[t])
 
     def set_state_slot(self, t, state):
         """Copy an env state dict (HipCoverageEnv.get_state(): pos, vel, energy, done) into slot t."""
-        if self.compact:
+        if self.store_state:
             self.state_pos[t].copy_(state["pos"]); self.state_vel[t].copy_(state["vel"])
             self.state_energy[t].copy_(state["energy"]); self.state_done[t].copy_(state["done"])
 
@@ -137,8 +139,7 @@ class SharedReplayBuffer(object):
 
     def invalidate_features(self):
         """Drop the cached per-chunk features (call whenever the state slots are about to be rewritten)."""
-        if self.compact:
-            self._feat_cache.clear()
+        self._feat_cache.clear()
 
     def obs_rows(self, t0, t1):
         """[(t1-t0), E, N, D] observations of slots t0..t1-1; compact: regenerated from state into a reused chunk."""
@@ -217,9 +218,10 @@ class SharedReplayBuffer(object):
 
     def after_update(self):
         """shared_buffer.py:142-152: the last slot becomes slot 0."""
-        if self.compact:
+        if self.store_state:
             for a in (self.state_pos, self.state_vel, self.state_energy, self.state_done):
                 a[0].copy_(a[-1])
+        if self.compact:
             self._cur_slot = 0 if self._cur_slot == self.episode_length else self._cur_slot
         else:
             self.obs[0].copy_(self.obs[-1])

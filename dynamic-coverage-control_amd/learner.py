@@ -114,7 +114,7 @@ class Learner:
         bcfg = copy.deepcopy(self.cfg)
         bcfg.n_rollout_threads = envs.n_envs
         structured = bool(getattr(self.cfg, "structured_input", False))
-        compact = bool(getattr(self.cfg, "compact_obs", False)) or structured
+        compact = bool(getattr(self.cfg, "compact_obs", False))
         return SharedReplayBuffer(bcfg, envs.observation_space[0], envs.share_observation_space[0], envs.action_space[0],
                                   compact=compact, n_pois=envs.n_pois, expander=envs.env.expand_obs if compact else None,
                                   featurizer=envs.env.obs_features if structured else None)
@@ -151,8 +151,10 @@ class Learner:
         cov_max = torch.zeros(r_envs.n_envs, dtype=torch.float32, device=ptu.device)
         for cur_step in range(self.max_ep_len):
             values, actions, action_log_probs = self.collect(cur_step, r_buffer)
-            out = r_envs.step_device(actions, obs_out=None if r_buffer.structured else r_buffer.obs_slot(cur_step + 1),
-                                     extra_out=r_buffer.state_slot(cur_step + 1), want_obs=not r_buffer.structured)
+            # rows are written unless the policy reads features AND the buffer does not keep rows
+            want_rows = not (r_buffer.structured and r_buffer.compact)
+            out = r_envs.step_device(actions, obs_out=r_buffer.obs_slot(cur_step + 1) if want_rows else None,
+                                     extra_out=r_buffer.state_slot(cur_step + 1), want_obs=want_rows)
             self.insert((out, values, actions, action_log_probs), r_buffer)
             rew_sum += out["reward"].double().mean()
             cov_max = torch.maximum(cov_max, out["coverage"])
@@ -194,7 +196,7 @@ class Learner:
     def warmup(self, r_buffer, r_envs):
         """reset every env; obs -> slot 0 (learner.py:216-225; share_obs is a view of obs here)."""
         r_envs.reset_device(r_buffer.obs_slot(0))
-        if r_buffer.compact:
+        if r_buffer.store_state:
             r_buffer.set_state_slot(0, r_envs.env.get_state())
         r_buffer.masks[0].fill_(1.0)
         r_buffer.step = 0

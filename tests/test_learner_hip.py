@@ -214,6 +214,7 @@ def test_compact_state_buffer_trains_like_the_full_buffer():
     from learner import Learner
     kw = dict(n_rollout_threads=48, n_eval_rollout_threads=0, num_agents=8, num_pois=64, max_ep_len=25, n_iters=1,
               ppo_epoch=3, algo_hidden_size=64, save_model=False, seed=5, cache_normalized_inputs=False)
+    kw["structured_input"] = False          # dense first layers on rows: stored (full) vs regenerated per chunk (comp)
     full = Learner(_cfg(**kw))
     comp = Learner(_cfg(**dict(kw, compact_obs=True, update_chunk_steps=7)))
     for (k, a), (_, b) in zip(full.policy.actor.state_dict().items(), comp.policy.actor.state_dict().items()):
@@ -248,8 +249,8 @@ def test_structured_input_trains_like_the_full_buffer():
     from learner import Learner
     kw = dict(n_rollout_threads=40, n_eval_rollout_threads=0, num_agents=8, num_pois=64, max_ep_len=20, n_iters=1,
               ppo_epoch=3, algo_hidden_size=64, save_model=False, seed=9, cache_normalized_inputs=False)
-    st = Learner(_cfg(**dict(kw, structured_input=True, update_chunk_steps=8)))
-    full = Learner(_cfg(**kw))
+    st = Learner(_cfg(**dict(kw, structured_input=True, compact_obs=True, update_chunk_steps=8)))
+    full = Learner(_cfg(**dict(kw, structured_input=False)))
     torch.manual_seed(4)
     r = st.rollout(st.rl_buffer, st.train_envs)
     sb, fb = st.rl_buffer, full.rl_buffer
@@ -318,6 +319,7 @@ def test_structured_learner_full_train_loop_with_eval_envs(tmp_path):
     lr = Learner(cfg)
     lr.train()
     assert lr.rl_buffer.structured and lr.test_buffer.structured and len(lr._graphs) == 2
+    assert lr.rl_buffer.obs is not None and not lr.rl_buffer.compact       # shipped default: features AND rows
     assert os.path.exists(os.path.join(lr.output_path, "models_3.pt", "agent.pkl"))
     lr2 = Learner(_cfg(**dict(vars(cfg), save_model=False, seed=7)))
     lr2.load_checkpoint(os.path.join(lr.output_path, "models_3.pt", "resume.pt"))
