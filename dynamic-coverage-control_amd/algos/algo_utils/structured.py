@@ -118,16 +118,45 @@ class _FoldedWeights(torch.autograd.Function):
 
 
 def folded_weights(base, layout, Nb):
-    """(w_h, w_ed, const, s, c, eps) of the structured first layer of `base` (see _FoldedWeights)."""
+    """(w_h, w_ed, const, s, c, eps) of the structured first layer of `base` (see _FoldedWeights).
+
+    With autograd enabled this is a graph node.  Without (rollout / evaluation) the result only changes when the
+    parameters do, so it is cached on `base` keyed by the parameters' version counters and refreshed IN PLACE -- the
+    tensors keep their addresses, which lets a captured hipGraph of the rollout keep reading them (the learner calls
+    refresh_folded_weights() before every replay, since a replay runs no Python)."""
     lin = base.mlp.fc1[0]
     if base._use_feature_normalization:
         ln = base.feature_norm
         gamma, beta, eps = ln.weight, ln.bias, ln.eps
     else:
         gamma = beta = eps = None
-    out = _FoldedWeights.apply(lin.weight, lin.bias, gamma, beta, layout.poi(lin.weight), layout.m_energy, Nb, layout.HD,
-                               layout.M)
-    return out + (eps,)
+    args = (lin.weight, lin.bias, gamma, beta, layout.poi(lin.weight), layout.m_energy, Nb, layout.HD, layout.M)
+    if torch.is_grad_enabled() or torch.is_autocast_enabled():
+        return _FoldedWeights.apply(*args) + (eps,)
+    versions = tuple(-1 if t is None else t._version for t in (lin.weight, lin.bias, gamma, beta))
+    cache = base.__dict__.setdefault("_folded_cache", {})
+    hit = cache.get(Nb)
+    if hit is None or hit[0] != versions or hit[1][0].device != lin.weight.device or hit[1][0].dtype != lin.weight.dtype:
+        with torch.no_grad():
+            fresh = _FoldedWeights.apply(*args)
+        if hit is not None and all(a.shape == b.shape and a.device == b.device and a.dtype == b.dtype
+                                   for a, b in zip(hit[1], fresh)):
+            for a, b in zip(hit[1], fresh):
+                a.copy_(b)
+            hit = (versions, hit[1])
+        else:
+            hit = (versions, tuple(t.clone() for t in fresh))
+        cache[Nb] = hit
+    return hit[1] + (eps,)
+
+
+def refresh_folded_weights(actor, critic):
+    """Bring the inference caches of both networks up to date (call before replaying a captured rollout)."""
+    with torch.no_grad():
+        if getattr(actor, "obs_layout", None) is not None:
+            folded_weights(actor.base, actor.obs_layout, 1)
+        if getattr(critic, "obs_layout", None) is not None:
+            folded_weights(critic.base, critic.obs_layout, critic.obs_layout.N)
 
 
 def _tail(blk, z, bias=None):

@@ -167,6 +167,9 @@ class Learner:
             raise NotImplementedError("rendering is out of scope (no display on a GPU node)")
         key = id(r_buffer)
         r_buffer.invalidate_features()     # host-side cache: must also be dropped when the rollout is a graph replay
+        if r_buffer.structured:            # parameter-derived inference tensors the (captured) rollout reads
+            from algos.algo_utils.structured import refresh_folded_weights
+            refresh_folded_weights(self.policy.actor, self.policy.critic)
         if self.use_hip_graph and key in self._graphs:
             graph, stats = self._graphs[key]
             graph.replay()

@@ -183,6 +183,11 @@ def test_graph_replay_does_not_reuse_stale_features():
         fresh = lr.train_envs.env.obs_features(b.state_pos[:T].reshape(n, 4, 2), b.state_vel[:T].reshape(n, 4, 2),
                                                 b.state_energy[:T].reshape(n, -1), b.state_done[:T].reshape(n, -1))
         assert torch.equal(f["head"], fresh["head"]) and torch.equal(f["stats"], fresh["stats"]), it
+    # the replayed rollout used the CURRENT parameters (the inference cache of the folded first-layer weights is
+    # refreshed in place before every replay): values stored for slot 3 == an autograd-path forward now
+    lr.rollout(b, lr.train_envs)
+    v_now = lr.policy.critic(b.features_at(3))[0].detach()
+    np.testing.assert_allclose(b.value_preds[3, :, 0, 0].cpu().numpy(), v_now.view(-1).cpu().numpy(), rtol=1e-5, atol=1e-6)
     assert lr.use_hip_graph and len(lr._graphs) == 1
     ptu.set_gpu_mode(False)
 

@@ -91,3 +91,29 @@ def test_features_from_obs_layout(oracle_mod):
     var, mean = torch.var_mean(obs.double(), -1, unbiased=False)
     np.testing.assert_allclose(f["stats"][..., 0].numpy(), mean.numpy(), rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose((f["stats"][..., 1] / lay.D).numpy(), var.numpy(), rtol=1e-10)
+
+
+def test_inference_cache_of_folded_weights_tracks_parameter_updates(oracle_mod):
+    """Without autograd the weight-side tensors are cached per parameter version and refreshed IN PLACE (a captured
+    rollout graph keeps reading the same addresses)."""
+    from algos.algo_utils import structured as S
+    obs, poi = _rows(oracle_mod, 4, 20, 6, 2)
+    lay = S.ObsLayout(4, 20, poi, 5.0)
+    base = _base(lay.D, True, hidden=16)
+    feats = S.features_from_obs(obs.float(), lay)
+    with torch.no_grad():
+        a1 = S.folded_weights(base, lay, 1)
+        a2 = S.folded_weights(base, lay, 1)
+        assert all(x is y for x, y in zip(a1[:5], a2[:5]))                    # cache hit: the very same tensors
+        out1 = S.actor_trunk(base, lay, feats).clone()
+        ptrs = [t.data_ptr() for t in a1[:5]]
+        base.mlp.fc1[0].weight.mul_(1.5)                                       # in-place update (like an optimizer step)
+        base.feature_norm.bias.add_(0.1)
+        a3 = S.folded_weights(base, lay, 1)
+        assert [t.data_ptr() for t in a3[:5]] == ptrs                          # refreshed in place
+        out2 = S.actor_trunk(base, lay, feats)
+    ref = S.actor_trunk(base, lay, feats)                                      # autograd path: no cache involved
+    np.testing.assert_allclose(out2.numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
+    assert float((out1 - out2).abs().max()) > 1e-3
+    dense = base(obs.float().view(-1, lay.D))
+    np.testing.assert_allclose(out2.numpy(), dense.detach().numpy(), rtol=2e-4, atol=2e-5)
