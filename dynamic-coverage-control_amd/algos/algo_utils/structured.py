@@ -150,6 +150,17 @@ def folded_weights(base, layout, Nb):
     return hit[1] + (eps,)
 
 
+def invalidate_folded_weights(*modules):
+    """Mark the inference caches stale but keep their tensors (addresses).  The optimizer step calls this: parameter
+    version counters are not enough, because a step replayed inside a hipGraph updates the parameters without running
+    the Python that bumps them."""
+    for m in modules:
+        cache = getattr(m, "base", m).__dict__.get("_folded_cache")
+        if cache:
+            for k, (_, tensors) in list(cache.items()):
+                cache[k] = (None, tensors)
+
+
 def refresh_folded_weights(actor, critic):
     """Bring the inference caches of both networks up to date (call before replaying a captured rollout)."""
     with torch.no_grad():

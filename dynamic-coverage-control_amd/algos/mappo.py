@@ -23,6 +23,7 @@ import torch.nn as nn
 
 import utils.pytorch_utils as ptu
 from algos.algo_utils import fused
+from algos.algo_utils.structured import invalidate_folded_weights
 from algos.r_actor_critic import R_Actor, R_Critic
 from utils.util import get_gard_norm, huber_loss, mse_loss, update_linear_schedule
 from utils.valuenorm import ValueNorm
@@ -41,10 +42,16 @@ class MAPPOPolicy:
         self.obs_space, self.share_obs_space, self.act_space = obs_space, cent_obs_space, act_space
         self.actor = R_Actor(cfg, obs_space, act_space, ptu.device)
         self.critic = R_Critic(cfg, cent_obs_space, ptu.device)
-        self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=self.actor_lr, eps=self.opti_eps,
-                                                weight_decay=self.weight_decay)
-        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=self.critic_lr, eps=self.opti_eps,
-                                                 weight_decay=self.weight_decay)
+        # cfg.use_hip_graph_update: each PPO epoch (forward, backward, clipping, Adam) is replayed as one hipGraph.  That
+        # needs Adam's step counter and learning rate on the device (capturable=True, tensor lr): same update rule,
+        # bias corrections evaluated in float32 on the GPU instead of Python floats.
+        self.capturable = bool(getattr(cfg, "use_hip_graph_update", False)) and ptu.device.type == "cuda"
+        mk_lr = (lambda v: torch.tensor(float(v), device=ptu.device)) if self.capturable else (lambda v: v)
+        extra = dict(capturable=True) if self.capturable else {}
+        self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=mk_lr(self.actor_lr), eps=self.opti_eps,
+                                                weight_decay=self.weight_decay, **extra)
+        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=mk_lr(self.critic_lr), eps=self.opti_eps,
+                                                 weight_decay=self.weight_decay, **extra)
 
     def enable_structured_input(self, layout):
         """Let actor and critic accept compact features (algo_utils/structured.py) in place of observation rows."""
@@ -139,6 +146,13 @@ class MAPPOTrainer:
         # > 0: visit the batch in chunks of this many rollout steps with gradient accumulation (exact);
         # required by (and defaulted for) the compact-state rollout buffer
         self.update_chunk_steps = int(getattr(cfg, "update_chunk_steps", 0))
+        # replay each chunked PPO epoch as one hipGraph (single GPU, fp32; needs the policy's capturable optimizers)
+        self.graph_update = (bool(getattr(cfg, "use_hip_graph_update", False)) and getattr(policy, "capturable", False)
+                             and _dist() is None and not bool(getattr(cfg, "amp_bf16", False)))
+        # large batches are GPU-bound (c3: 37 ms of kernels per epoch) and would only pay the graph's private memory pool;
+        # the replay is for launch-bound batches (shipped task, 16 envs: ~350 launches of a few us per epoch)
+        self.graph_update_max_rows = int(getattr(cfg, "graph_update_max_rows", 1000000))
+        self._epoch_graphs, self._adv_static = {}, {}
         self.value_normalizer = ValueNorm(1, device=ptu.device) if self._use_valuenorm else None
 
     # ---- losses ---------------------------------------------------------------------------------
@@ -224,6 +238,7 @@ class MAPPOTrainer:
             actor_grad_norm, critic_grad_norm = get_gard_norm(actor_params), get_gard_norm(critic_params)
         self.policy.actor_optimizer.step()
         self.policy.critic_optimizer.step()
+        invalidate_folded_weights(self.policy.actor, self.policy.critic)
         return actor_grad_norm, critic_grad_norm
 
     def ppo_update(self, sample, update_actor=True, prenormalized=False):
@@ -273,6 +288,45 @@ class MAPPOTrainer:
         actor_grad_norm, critic_grad_norm = self._optimizer_step()
         return acc[0], critic_grad_norm, acc[1], acc[2], actor_grad_norm, acc[3]
 
+    def _epoch_metrics(self, buffer, advantages, update_actor):
+        vl, cgn, pl, ent, agn, ratio = self.ppo_update_chunked(buffer, advantages, update_actor)
+        dev = vl.device
+        return torch.stack([vl.double(), pl.double(), ent.double(), torch.as_tensor(agn, device=dev).double(),
+                            torch.as_tensor(cgn, device=dev).double(), ratio.double()])
+
+    def _epoch(self, buffer, advantages, update_actor):
+        """One chunked full-batch PPO epoch -> metrics [6] (float64).  With use_hip_graph_update the epoch is captured
+        after its first eager execution and replayed from then on (its inputs are static: buffer arrays, the persistent
+        per-chunk feature buffers, the static advantage buffer, parameters / optimizer state updated in place)."""
+        rows = buffer.episode_length * buffer.n_rollout_threads * buffer.num_agents
+        if not self.graph_update or rows > self.graph_update_max_rows:
+            return self._epoch_metrics(buffer, advantages, update_actor)
+        key = (id(buffer), bool(update_actor), advantages.data_ptr())
+        hit = self._epoch_graphs.get(key)
+        if hit is not None:
+            hit[0].replay()
+            invalidate_folded_weights(self.policy.actor, self.policy.critic)   # the replay stepped the parameters
+            return hit[1]
+        m = self._epoch_metrics(buffer, advantages, update_actor)       # really executes (and warms allocator / hipBLASLt)
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                ms = self._epoch_metrics(buffer, advantages, update_actor)
+            self._epoch_graphs[key] = (g, ms)
+        except Exception as e:      # an optimisation only: keep training eagerly
+            print("hipGraph capture of the PPO epoch failed (%s); continuing eagerly" % e)
+            self.graph_update = False
+            torch.cuda.synchronize()
+        return m
+
+    def _static_advantages(self, buffer, advantages):
+        buf = self._adv_static.get(id(buffer))
+        if buf is None or buf.shape != advantages.shape:
+            buf = self._adv_static[id(buffer)] = torch.empty_like(advantages)
+        buf.copy_(advantages)
+        return buf
+
     # ---- one training phase -------------------------------------------------------------------------
     def normalized_advantages(self, buffer):
         """mappo.py:190-198: adv = returns - denorm(V); (adv - mean) / (std + 1e-5) over active entries
@@ -303,11 +357,16 @@ class MAPPOTrainer:
                 raise NotImplementedError("chunked / compact-state updates are full-batch (num_mini_batch: 1)")
             if self.update_chunk_steps <= 0:   # rows are regenerated per chunk: keep them small; features are tiny
                 self.update_chunk_steps = buffer.episode_length if getattr(buffer, "structured", False) else 10
+            if getattr(buffer, "structured", False):
+                # per-chunk state features: parameter-free, shared by all epochs, recomputed IN PLACE after a rollout.
+                # Done here (not lazily inside the epoch) because a replayed epoch graph runs no Python.
+                T, step = buffer.episode_length, max(1, int(self.update_chunk_steps))
+                for t0 in range(0, T, step):
+                    buffer.features_rows(t0, min(T, t0 + step))
+            if self.graph_update:
+                advantages = self._static_advantages(buffer, advantages)
             for _ in range(self.ppo_epoch):
-                vl, cgn, pl, ent, agn, ratio = self.ppo_update_chunked(buffer, advantages, update_actor)
-                acc += torch.stack([vl.double(), pl.double(), ent.double(),
-                                    torch.as_tensor(agn, device=acc.device).double(),
-                                    torch.as_tensor(cgn, device=acc.device).double(), ratio.double()])
+                acc += self._epoch(buffer, advantages, update_actor)
             acc /= self.ppo_epoch
             for k, v in zip(("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"),
                             acc.tolist()):

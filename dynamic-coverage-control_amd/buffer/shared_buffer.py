@@ -49,7 +49,7 @@ class SharedReplayBuffer(object):
         self._featurize = featurizer
         self.structured = featurizer is not None
         self.store_state = self.compact or self.structured
-        self._feat_cache = {}
+        self._feat_cache, self._feat_valid = {}, set()
         if self.store_state:
             if not self._shared_is_view or n_pois is None or (self.compact and expander is None):
                 raise ValueError("state-storing buffer needs share_obs == concat(obs), n_pois and (compact) an expander "
@@ -125,21 +125,23 @@ class SharedReplayBuffer(object):
         return self._featurize(self.state_pos[t], self.state_vel[t], self.state_energy[t], self.state_done[t])
 
     def features_rows(self, t0, t1):
-        """Features of slots t0..t1-1 flattened over (step, env); cached until the next rollout overwrites the state
-        (they do not depend on the parameters, so all PPO epochs share them)."""
+        """Features of slots t0..t1-1 flattened over (step, env).  They do not depend on the parameters, so all PPO
+        epochs of an iteration share them; the buffers are persistent (recomputed in place after every rollout), which
+        keeps their addresses valid for a captured hipGraph of the epoch."""
         key = (t0, t1)
         f = self._feat_cache.get(key)
-        if f is None:
+        if f is None or key not in self._feat_valid:
             E, N = self.n_rollout_threads, self.num_agents
             n = (t1 - t0) * E
-            f = self._feat_cache[key] = self._featurize(
-                self.state_pos[t0:t1].reshape(n, N, 2), self.state_vel[t0:t1].reshape(n, N, 2),
-                self.state_energy[t0:t1].reshape(n, -1), self.state_done[t0:t1].reshape(n, -1))
+            f = self._featurize(self.state_pos[t0:t1].reshape(n, N, 2), self.state_vel[t0:t1].reshape(n, N, 2),
+                                self.state_energy[t0:t1].reshape(n, -1), self.state_done[t0:t1].reshape(n, -1), f)
+            self._feat_cache[key] = f
+            self._feat_valid.add(key)
         return f
 
     def invalidate_features(self):
-        """Drop the cached per-chunk features (call whenever the state slots are about to be rewritten)."""
-        self._feat_cache.clear()
+        """Mark the cached per-chunk features stale (call whenever the state slots are about to be rewritten)."""
+        self._feat_valid.clear()
 
     def obs_rows(self, t0, t1):
         """[(t1-t0), E, N, D] observations of slots t0..t1-1; compact: regenerated from state into a reused chunk."""

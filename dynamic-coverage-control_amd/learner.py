@@ -287,6 +287,10 @@ class Learner:
         self.policy.actor.load_state_dict(ck["actor"]); self.policy.critic.load_state_dict(ck["critic"])
         self.policy.actor_optimizer.load_state_dict(ck["actor_optimizer"])
         self.policy.critic_optimizer.load_state_dict(ck["critic_optimizer"])
+        if getattr(self.policy, "capturable", False):     # capturable Adam: the learning rate lives on the device
+            for opt in (self.policy.actor_optimizer, self.policy.critic_optimizer):
+                for g in opt.param_groups:
+                    g["lr"] = torch.as_tensor(float(g["lr"]), dtype=torch.float32, device=ptu.device)
         if ck["value_normalizer"] is not None and self.trainer.value_normalizer is not None:
             self.trainer.value_normalizer.load_state_dict(ck["value_normalizer"])
         torch.set_rng_state(ck["rng_torch"]); np.random.set_state(ck["rng_numpy"])

@@ -174,7 +174,7 @@ def test_graph_replay_does_not_reuse_stale_features():
     b = lr.rl_buffer
     for it in range(3):        # eager (+capture), then two replays
         lr.rollout(b, lr.train_envs)
-        assert b._feat_cache == {}
+        assert b._feat_valid == set()
         lr.trainer.prep_training()
         lr.trainer.train(b)        # (not rl_update: its after_update() rewrites slot 0)
         T = b.episode_length
@@ -332,4 +332,34 @@ def test_structured_learner_full_train_loop_with_eval_envs(tmp_path):
         assert torch.equal(a, b), k
     res = lr2.evaluate(steps=10)
     assert 0.0 <= res["coverage_rate"] <= 1.0
+    ptu.set_gpu_mode(False)
+
+
+def test_graph_replayed_ppo_epochs_equal_eager_epochs():
+    """use_hip_graph_update: the captured epoch (forward, backward, clip, capturable Adam with a device lr) replayed
+    N times == the same epochs issued eagerly -- parameters, ValueNorm and metrics bit for bit, across an LR decay."""
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    kw = dict(n_rollout_threads=24, n_eval_rollout_threads=0, num_agents=4, num_pois=20, max_ep_len=20, n_iters=3,
+              ppo_epoch=4, algo_hidden_size=64, save_model=False, seed=13)
+    g = Learner(_cfg(**kw))
+    e = Learner(_cfg(**kw))
+    e.trainer.graph_update = False                     # same capturable optimizers, epochs issued eagerly
+    assert g.trainer.graph_update and g.policy.capturable and torch.is_tensor(g.policy.actor_optimizer.param_groups[0]["lr"])
+    for it in (1, 2, 3):
+        for lr in (g, e):
+            lr.policy.lr_decay(it, 3)
+            torch.manual_seed(100 + it)
+            lr.rollout(lr.rl_buffer, lr.train_envs)
+        ig, ie = g.rl_update(), e.rl_update()
+        for k in ig:
+            assert ig[k] == ie[k], (it, k, ig[k], ie[k])
+        for (k, a), (_, b) in zip(g.policy.actor.state_dict().items(), e.policy.actor.state_dict().items()):
+            assert torch.equal(a, b), (it, k)
+        for (k, a), (_, b) in zip(g.policy.critic.state_dict().items(), e.policy.critic.state_dict().items()):
+            assert torch.equal(a, b), (it, k)
+        assert torch.equal(g.trainer.value_normalizer.running_mean, e.trainer.value_normalizer.running_mean)
+    assert g.trainer.graph_update and len(g.trainer._epoch_graphs) == 1
+    assert float(g.policy.actor_optimizer.param_groups[0]["lr"]) == 0.0        # lr0 * (1 - 3/3)
     ptu.set_gpu_mode(False)
