@@ -458,6 +458,38 @@ __global__ __launch_bounds__(kBlock) void ppo_policy_loss_k(const float* __restr
     }
 }
 
+// ---- rollout glue: sample + log-prob + buffer insert in one launch, reward / mask record in another -------------------
+// (Learner.collect / insert, learner.py:227-276: ~18 element-wise launches per env step otherwise.)
+__global__ __launch_bounds__(kBlock) void rollout_sample_k(const float* __restrict__ mean, const float* __restrict__ logstd,
+                                                           const float* __restrict__ eps, const float* __restrict__ value,
+                                                           float* __restrict__ actions, float* __restrict__ logp,
+                                                           float* __restrict__ value_preds, long long R, int N, int A, int K) {
+    const long long r = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= R) return;
+    float lp = 0.f;
+#pragma unroll
+    for (int d = 0; d < kAMax; ++d)
+        if (d < A) {
+            const float ls = logstd[d], sd = expf(ls), mu = mean[r * A + d];
+            const float a = __fadd_rn(mu, __fmul_rn(sd, eps[r * A + d]));   // FixedNormal.sample: mean + std * randn (no fma)
+            actions[r * A + d] = a;
+            const float dev = a - mu;                             // Normal.log_prob on the rounded action, like torch
+            lp += -(dev * dev) / (2.f * sd * sd) - ls - 0.91893853320467274178f;
+        }
+    for (int k = 0; k < K; ++k) logp[r * K + k] = lp;
+    if (value_preds) value_preds[r] = value[r / N];              // one critic value per env, broadcast over its agents
+}
+
+__global__ __launch_bounds__(kBlock) void rollout_record_k(const float* __restrict__ reward, const unsigned char* __restrict__ done,
+                                                           float* __restrict__ rewards, float* __restrict__ masks_next,
+                                                           long long R, int N) {
+    const long long r = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= R) return;
+    const long long e = r / N;
+    rewards[r] = reward[e];
+    masks_next[r] = done[e] ? 0.f : 1.f;                         // masks = 1 - done (learner.py:262-264)
+}
+
 // ---- actor first block from compact features -------------------------------------------------------------------
 // z[r,c] = rstd_in[r] * (sum_k head[r,k] Wh[c,k] + G[e,c] - mean_in[r] s[c]) + cb[c];   h = LayerNorm(ReLU(z))
 // One wave per env: G[e] is loaded once for its N agent rows and (backward) dG[e] is summed in registers.
@@ -871,6 +903,24 @@ DCC_API int dcc_ppo_policy_loss(const float* mean, const float* logstd, const fl
                        active, clip, dmean, workspace, (long long)R, (int)A, (int)K);
     const long long nseg = reduce_stage1(workspace, blocks, kPpoP, kPpoP, st_);
     hipLaunchKernelGGL(reduce_partials_k, dim3(1), dim3(kBlock), 0, st_, workspace, nseg, kPpoP, kSegWaves * kPpoP, sums);
+    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+}
+
+DCC_API int dcc_rollout_sample(const float* mean, const float* logstd, const float* eps, const float* value, float* actions,
+                               float* logp, float* value_preds, int64_t R, int32_t N, int32_t A, int32_t K, void* stream) {
+    if (!mean || !logstd || !eps || !actions || !logp || R < 1 || N < 1 || (value_preds && !value)) return kEINVAL;
+    if (A < 1 || A > kAMax || K < 1 || K > kAMax) return kEUNSUPPORTED;
+    hipLaunchKernelGGL(rollout_sample_k, dim3((unsigned)((R + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), mean, logstd, eps, value, actions, logp, value_preds, (long long)R,
+                       (int)N, (int)A, (int)K);
+    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+}
+
+DCC_API int dcc_rollout_record(const float* reward, const uint8_t* done, float* rewards, float* masks_next, int64_t R,
+                               int32_t N, void* stream) {
+    if (!reward || !done || !rewards || !masks_next || R < 1 || N < 1) return kEINVAL;
+    hipLaunchKernelGGL(rollout_record_k, dim3((unsigned)((R + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), reward, done, rewards, masks_next, (long long)R, (int)N);
     return hipGetLastError() == hipSuccess ? 0 : kEHIP;
 }
 

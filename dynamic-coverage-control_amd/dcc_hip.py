@@ -43,7 +43,8 @@ class EnvOut(ctypes.Structure):
 EXPORTS = ["dcc_obs_expand", "dcc_gae_compute", "dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
            "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout", "dcc_env_get_state",
            "dcc_env_set_state", "dcc_env_bytes_per_step", "dcc_obs_features",
-           "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_relu_ln_head_fwd", "dcc_relu_ln_head_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd", "dcc_ppo_policy_loss"]
+           "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_relu_ln_head_fwd", "dcc_relu_ln_head_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd", "dcc_ppo_policy_loss",
+           "dcc_rollout_sample", "dcc_rollout_record"]
 
 _lib = None
 
@@ -83,6 +84,8 @@ def load_library(path=None):
     L.dcc_relu_ln_head_fwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, _vp, _vp, i64, i32, i32, _vp]
     L.dcc_relu_ln_head_bwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, _vp, _vp, _vp, _vp, i64, i32, i32, _vp]
     L.dcc_ppo_policy_loss.argtypes = [_vp] * 6 + [f32, _vp, _vp, _vp, i64, i32, i32, _vp]
+    L.dcc_rollout_sample.argtypes = [_vp] * 7 + [i64, i32, i32, i32, _vp]
+    L.dcc_rollout_record.argtypes = [_vp] * 4 + [i64, i32, _vp]
     L.dcc_mlp_workspace_floats.argtypes = [i32, i32]
     L.dcc_mlp_workspace_floats.restype = i64
     L.dcc_actor_l1_fwd.argtypes = [_vp] * 8 + [f32, f32, i32, _vp, i64, i32, i32, i32, _vp]
@@ -409,6 +412,27 @@ def ppo_policy_loss(mean, logstd, actions, old_logp, adv, active, clip):
                                                   _ptr(None if active is None else _f32c(active, "active")), clip, _ptr(dmean),
                                                   _ptr(sums), _ptr(ws), R, A, K, _stream()), "dcc_ppo_policy_loss")
     return dmean, sums
+
+
+def rollout_sample(mean, logstd, eps, value, actions_out, logp_out, value_preds_out, n_agents):
+    """Sample + log-prob + insert into the buffer slots in one launch (include/dcc_mlp.h: dcc_rollout_sample)."""
+    R, A = mean.shape
+    K = logp_out.numel() // R
+    for t, nm in ((mean, "mean"), (eps, "eps"), (actions_out, "actions"), (logp_out, "logp")):
+        _f32c(t, nm)
+    with torch.cuda.device(mean.device):
+        _check(load_library().dcc_rollout_sample(_ptr(mean), _ptr(_f32c(logstd, "logstd")), _ptr(eps), _ptr(value),
+                                                 _ptr(actions_out), _ptr(logp_out), _ptr(value_preds_out), R, n_agents, A, K,
+                                                 _stream()), "dcc_rollout_sample")
+
+
+def rollout_record(reward, done, rewards_out, masks_out, n_agents):
+    R = rewards_out.numel()
+    if reward.dtype != torch.float32 or done.dtype != torch.uint8 or not rewards_out.is_contiguous() or not masks_out.is_contiguous():
+        raise ValueError("rollout_record: reward f32 [E], done u8 [E], contiguous float32 outputs")
+    with torch.cuda.device(reward.device):
+        _check(load_library().dcc_rollout_record(_ptr(reward), _ptr(done), _ptr(rewards_out), _ptr(masks_out), R, n_agents,
+                                                 _stream()), "dcc_rollout_record")
 
 
 def actor_l1_fwd(head, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, D):

@@ -149,13 +149,23 @@ class Learner:
         self.warmup(r_buffer, r_envs)
         rew_sum = torch.zeros((), dtype=torch.float64, device=ptu.device)
         cov_max = torch.zeros(r_envs.n_envs, dtype=torch.float32, device=ptu.device)
+        fused_glue = self._fused_glue_ok(r_buffer)
         for cur_step in range(self.max_ep_len):
-            values, actions, action_log_probs = self.collect(cur_step, r_buffer)
+            if fused_glue:      # sample + log-prob + buffer insert in one launch (dcc_rollout_sample)
+                actions = self.collect_into(cur_step, r_buffer)
+            else:
+                values, actions, action_log_probs = self.collect(cur_step, r_buffer)
             # rows are written unless the policy reads features AND the buffer does not keep rows
             want_rows = not (r_buffer.structured and r_buffer.compact)
             out = r_envs.step_device(actions, obs_out=r_buffer.obs_slot(cur_step + 1) if want_rows else None,
                                      extra_out=r_buffer.state_slot(cur_step + 1), want_obs=want_rows)
-            self.insert((out, values, actions, action_log_probs), r_buffer)
+            if fused_glue:      # rewards / masks of the env step into their buffer slots (dcc_rollout_record)
+                import dcc_hip
+                dcc_hip.rollout_record(out["reward"], out["done"], r_buffer.rewards[cur_step], r_buffer.masks[cur_step + 1],
+                                       self.n_agents)
+                r_buffer.step = (cur_step + 1) % r_buffer.episode_length
+            else:
+                self.insert((out, values, actions, action_log_probs), r_buffer)
             rew_sum += out["reward"].double().mean()
             cov_max = torch.maximum(cov_max, out["coverage"])
         self.compute(r_buffer)
@@ -224,6 +234,32 @@ class Learner:
                 so = r_buffer.share_obs_env_at(cur_step).unsqueeze(1).expand(E, N, -1)
                 values = self.policy.critic(so.reshape(E * N, -1))[0].view(E, N, 1)
         return values.float(), actions.float().view(E, N, -1).contiguous(), logp.float().view(E, N, 1)
+
+    def _fused_glue_ok(self, r_buffer):
+        from algos.algo_utils import fused
+        return (ptu.device.type == "cuda" and fused.ENABLED and self.trainer.dedup_critic and not self.trainer.amp_bf16
+                and r_buffer.act_dim <= fused.HEAD_MAX_OUT)
+
+    @torch.no_grad()
+    def collect_into(self, cur_step, r_buffer):
+        """collect() + the policy-side half of insert() with the element-wise work in ONE HIP launch: action mean and
+        value from the networks, then a = mean + std * eps, log pi(a), and the writes into the buffer's action /
+        log-prob / value slots of this step (include/dcc_mlp.h: dcc_rollout_sample).  Returns the action slot."""
+        import dcc_hip
+        self.trainer.prep_rollout()
+        E, N = r_buffer.n_rollout_threads, self.n_agents
+        if r_buffer.structured:
+            x_actor = x_critic = r_buffer.features_at(cur_step)
+        else:
+            x_actor = r_buffer.obs_at(cur_step).view(E * N, -1)
+            x_critic = r_buffer.share_obs_env_at(cur_step)
+        mean = self.policy.actor._mean(x_actor)
+        value = self.policy.critic(x_critic)[0]
+        eps = torch.randn_like(mean)
+        logstd = self.policy.actor.act.action_out.logstd._bias.view(-1)
+        dcc_hip.rollout_sample(mean, logstd, eps, value.view(E), r_buffer.actions[cur_step], r_buffer.action_log_probs[cur_step],
+                               r_buffer.value_preds[cur_step], N)
+        return r_buffer.actions[cur_step]
 
     def insert(self, data, r_buffer):
         """masks = 0 where the env finished (learner.py:254-276); obs[t+1] is already in place."""

@@ -82,6 +82,18 @@ DCC_API int dcc_ppo_policy_loss(const float* mean, const float* logstd, const fl
                                 float* workspace, int64_t R, int32_t A, int32_t K, void* stream);
 
 /*
+ * Rollout glue (Learner.collect / insert, learner.py:227-276; SharedReplayBuffer.insert, buffer/shared_buffer.py:72-105).
+ * dcc_rollout_sample: actions = mean + exp(logstd) * eps (FixedNormal.sample), logp = sum_d Normal.log_prob (written to
+ *   all K columns of the buffer's [R,K] log-prob slot), value_preds[r] = value[r / N] (one critic value per env broadcast
+ *   over its N agents; value_preds may be NULL).  mean, eps, actions [R,A]; R = E*N rows; A, K <= 4.
+ * dcc_rollout_record: rewards[r] = reward[r / N], masks_next[r] = 1 - done[r / N] from the env step's [E] outputs.
+ */
+DCC_API int dcc_rollout_sample(const float* mean, const float* logstd, const float* eps, const float* value, float* actions,
+                               float* logp, float* value_preds, int64_t R, int32_t N, int32_t A, int32_t K, void* stream);
+DCC_API int dcc_rollout_record(const float* reward, const uint8_t* done, float* rewards, float* masks_next, int64_t R,
+                               int32_t N, void* stream);
+
+/*
  * Actor first block from compact features of n env states with N agents each (rows r = e*N + i):
  *   head  [n,N,HD] f32, HD = 4 + 2(N-1)      dcc_obs_features
  *   G     [n,H]    f32                       per-env term  poi_feat . [We;Wd]^T + const   (shared by the N agents)

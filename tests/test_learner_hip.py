@@ -363,3 +363,26 @@ def test_graph_replayed_ppo_epochs_equal_eager_epochs():
     assert g.trainer.graph_update and len(g.trainer._epoch_graphs) == 1
     assert float(g.policy.actor_optimizer.param_groups[0]["lr"]) == 0.0        # lr0 * (1 - 3/3)
     ptu.set_gpu_mode(False)
+
+
+def test_fused_rollout_glue_fills_the_buffer_like_collect_and_insert():
+    """dcc_rollout_sample / dcc_rollout_record (one launch each per step) leave the rollout buffer as the unfused
+    collect() + insert() do: same actions bit for bit (same RNG stream), same values / rewards / masks, log-probs to 1e-6."""
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    kw = dict(n_rollout_threads=40, n_eval_rollout_threads=0, num_agents=8, num_pois=64, max_ep_len=30, n_iters=1,
+              ppo_epoch=1, algo_hidden_size=64, save_model=False, seed=21, use_hip_graph=False)
+    a, b = Learner(_cfg(**kw)), Learner(_cfg(**kw))
+    assert a._fused_glue_ok(a.rl_buffer)
+    b._fused_glue_ok = lambda r_buffer: False
+    torch.manual_seed(77); ra = a.rollout(a.rl_buffer, a.train_envs)
+    torch.manual_seed(77); rb = b.rollout(b.rl_buffer, b.train_envs)
+    A, B = a.rl_buffer, b.rl_buffer
+    assert torch.equal(A.actions, B.actions)
+    for name in ("value_preds", "rewards", "masks", "returns"):
+        assert torch.equal(getattr(A, name), getattr(B, name)), name
+    np.testing.assert_allclose(A.action_log_probs.cpu().numpy(), B.action_log_probs.cpu().numpy(), rtol=0, atol=2e-6)
+    assert int((A.masks == 0).sum()) == int((B.masks == 0).sum()) and A.step == B.step
+    assert ra == rb
+    ptu.set_gpu_mode(False)
