@@ -62,7 +62,11 @@ def features_from_obs(obs, layout):
     x = obs.double()
     mean = x.mean(-1)
     m2 = ((x - mean.unsqueeze(-1)) ** 2).sum(-1)
-    return dict(head=head, poi_feat=poi_feat, stats=torch.stack([mean, m2], dim=-1))
+    xc = x.reshape(n, N * D)
+    cmean = xc.mean(-1)
+    cm2 = ((xc - cmean.unsqueeze(-1)) ** 2).sum(-1)
+    return dict(head=head, poi_feat=poi_feat, stats=torch.stack([mean, m2], dim=-1),
+                cstats=torch.stack([cmean, cm2], dim=-1))
 
 
 class _FoldedWeights(torch.autograd.Function):
@@ -216,9 +220,13 @@ def critic_trunk(base, layout, feats, head=None):
     w_h, w_ed, const, s_w, c, eps = folded_weights(base, layout, N)      # [H,N*HD], [H,2M], [H], [H], [H]
     z = fused.linear_w(head_f.reshape(n, N * HD), w_h) + (fused.linear_w(poi_feat, w_ed) + const)
     if eps is not None:
-        mean_i, m2_i = stats[..., 0], stats[..., 1]                            # [n, N] float64
-        mean = mean_i.mean(1, keepdim=True)
-        m2 = (m2_i + layout.D * (mean_i - mean) ** 2).sum(1, keepdim=True)     # pooled moments of the N*D-wide row
+        cstats = feats.get("cstats")
+        if cstats is not None:                                                 # pooled by dcc_obs_features
+            mean, m2 = cstats[:, 0:1], cstats[:, 1:2]
+        else:
+            mean_i, m2_i = stats[..., 0], stats[..., 1]                        # [n, N] float64
+            mean = mean_i.mean(1, keepdim=True)
+            m2 = (m2_i + layout.D * (mean_i - mean) ** 2).sum(1, keepdim=True) # pooled moments of the N*D-wide row
         rstd = torch.rsqrt(m2 / (N * layout.D) + eps)
         z = rstd.to(z.dtype) * (z - mean.to(z.dtype) * s_w) + c
     else:

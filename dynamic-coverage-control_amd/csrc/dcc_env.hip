@@ -783,7 +783,7 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : 4)) void dcc_obs_expand_ker
 // row ever being written (algos/algo_utils/structured.py has the algebra).  One wavefront per state.
 struct FeatParams {
     const double2* pos; const double2* vel; const float* energy; const uint8_t* done; const double2* poi;
-    float* head; float* poi_feat; double* stats;
+    float* head; float* poi_feat; double* stats; double* cstats;
     int n, N, M; float m_energy;
 };
 
@@ -802,6 +802,7 @@ __global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatPara
         for (int j = lane; j < M; j += 64) { f[j] = en[j]; f[M + j] = dn[j] ? 1.f : 0.f; }
     }
     const double me = (double)p.m_energy;
+    double my_mean = 0.0, my_m2 = 0.0;     // lane i keeps the moments of agent row i (for the pooled critic moments)
     for (int i = 0; i < N; ++i) {
         const double px = readlane_f64(mp.x, i), py = readlane_f64(mp.y, i);
         const float rx = (float)(mp.x - px), ry = (float)(mp.y - py);   // what the obs row holds for agent `lane`
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatPara
             if (lane == i) { h[0] = v0; h[1] = v1; h[2] = p0; h[3] = p1; }
             if (other) { const int k = lane < i ? lane : lane - 1; h[4 + 2 * k] = rx; h[5 + 2 * k] = ry; }
         }
-        if (!p.stats) continue;
+        if (!p.stats && !p.cstats) continue;
         // two-pass moments of the D float32 values of the row, accumulated in float64
         double s = 0.0;
         if (lane == i) s = ((double)v0 + (double)v1) + ((double)p0 + (double)p1);
@@ -832,7 +833,16 @@ __global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatPara
                   sq(dn[j] ? 1.0 : 0.0);
         }
         m2 = wave_sum_f64(m2);
-        if (lane == 0) { p.stats[((size_t)n * N + i) * 2] = mean; p.stats[((size_t)n * N + i) * 2 + 1] = m2; }
+        if (lane == 0 && p.stats) { p.stats[((size_t)n * N + i) * 2] = mean; p.stats[((size_t)n * N + i) * 2 + 1] = m2; }
+        if (lane == i) { my_mean = mean; my_m2 = m2; }
+    }
+    if (p.cstats) {
+        // moments of the centralised row = concatenation of the N agent rows (equal widths D): pooled mean, and
+        // sum of squared deviations by the parallel-variance identity
+        const double mean_e = wave_sum_f64(lane < N ? my_mean : 0.0) / (double)N;
+        const double dm = my_mean - mean_e;
+        const double m2_e = wave_sum_f64(lane < N ? my_m2 + (double)D * dm * dm : 0.0);
+        if (lane == 0) { p.cstats[(size_t)n * 2] = mean_e; p.cstats[(size_t)n * 2 + 1] = m2_e; }
     }
 }
 
@@ -1352,18 +1362,18 @@ int dcc_obs_expand(dcc_env* e, int64_t n, const double* pos, const double* vel, 
 }
 
 int dcc_obs_features(dcc_env* e, int64_t n, const double* pos, const double* vel, const float* energy,
-                     const uint8_t* done, float* head, float* poi_feat, double* stats, void* stream) {
+                     const uint8_t* done, float* head, float* poi_feat, double* stats, double* cstats, void* stream) {
     if (!e) return fail(DCC_EINVAL, "dcc_obs_features: null env");
     if (n < 1 || n > 0x7fffffffLL) return fail(DCC_EINVAL, "dcc_obs_features: n out of range");
     if (!pos || !vel || !energy || !done) return fail(DCC_EINVAL, "dcc_obs_features: null state pointer");
     if ((reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(vel)) & 15u)
         return fail(DCC_EINVAL, "dcc_obs_features: pos / vel must be 16-byte aligned");
-    if (!head && !poi_feat && !stats) return DCC_OK;
+    if (!head && !poi_feat && !stats && !cstats) return DCC_OK;
     DeviceGuard guard(e->device);
     FeatParams p;
     p.pos = reinterpret_cast<const double2*>(pos); p.vel = reinterpret_cast<const double2*>(vel);
     p.energy = energy; p.done = done; p.poi = e->d_poi;
-    p.head = head; p.poi_feat = poi_feat; p.stats = stats;
+    p.head = head; p.poi_feat = poi_feat; p.stats = stats; p.cstats = cstats;
     p.n = (int)n; p.N = e->cfg.n_agents; p.M = e->cfg.n_pois; p.m_energy = (float)e->cfg.m_energy;
     const int grid = (int)((n + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(dcc_obs_features_kernel, dim3(grid), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), p);

@@ -77,7 +77,7 @@ def load_library(path=None):
     L.dcc_gae_compute.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, ctypes.c_int32,
                                   ctypes.c_int64, _vp]
     L.dcc_obs_expand.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]
-    L.dcc_obs_features.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.dcc_obs_features.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     f32, i32, i64 = ctypes.c_float, ctypes.c_int32, ctypes.c_int64
     L.dcc_relu_ln_fwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, i64, i32, _vp]
     L.dcc_relu_ln_bwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, _vp, _vp, i64, i32, _vp]
@@ -194,7 +194,8 @@ class HipCoverageEnv:
 
     def obs_features(self, pos, vel, energy, done, out=None):
         """Compact policy-input features of n states (include/dcc_env.h: dcc_obs_features):
-        dict(head [n,N,4+2(N-1)] f32, poi_feat [n,2M] f32, stats [n,N,2] f64 = (mean, sum sq. dev.) of each obs row)."""
+        dict(head [n,N,4+2(N-1)] f32, poi_feat [n,2M] f32, stats [n,N,2] f64 = (mean, sum sq. dev.) of each obs row,
+        cstats [n,2] f64 = the same moments of the centralised row)."""
         n = pos.shape[0]
         want = ((pos, (n, self.N, 2), torch.float64), (vel, (n, self.N, 2), torch.float64),
                 (energy, (n, self.M), torch.float32), (done, (n, self.M), torch.uint8))
@@ -203,7 +204,7 @@ class HipCoverageEnv:
                 raise ValueError("obs_features: need contiguous %s %s on %s" % (shape, dt, self.device))
         HD = 4 + 2 * (self.N - 1)
         shapes = dict(head=((n, self.N, HD), torch.float32), poi_feat=((n, 2 * self.M), torch.float32),
-                      stats=((n, self.N, 2), torch.float64))
+                      stats=((n, self.N, 2), torch.float64), cstats=((n, 2), torch.float64))
         if out is None:
             out = {k: torch.empty(sh, dtype=dt, device=self.device) for k, (sh, dt) in shapes.items()}
         for k, (sh, dt) in shapes.items():
@@ -213,7 +214,7 @@ class HipCoverageEnv:
         with torch.cuda.device(self.device):
             _check(self.lib.dcc_obs_features(self._h, n, _ptr(pos), _ptr(vel), _ptr(energy), _ptr(done),
                                              _ptr(out.get("head")), _ptr(out.get("poi_feat")), _ptr(out.get("stats")),
-                                             _stream()), "dcc_obs_features")
+                                             _ptr(out.get("cstats")), _stream()), "dcc_obs_features")
         return out
 
     def _out_struct(self, out, K=None):

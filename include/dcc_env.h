@@ -143,10 +143,13 @@ DCC_API int dcc_obs_expand(dcc_env* env, int64_t n, const double* pos, const dou
  *   poi_feat [n,2M]         float32  PoI energies then PoI done flags (the obs columns that do not depend on the agent)
  *   stats    [n,N,2]        float64  (mean, sum of squared deviations) of the D float32 values of every row, i.e. the
  *                                    moments an input LayerNorm over the row needs (algos/algo_utils/mlp.py:45-49)
+ *   cstats   [n,2]          float64  the same two moments of the centralised row = the N agent rows concatenated
+ *                                    (learner.py:217-220), pooled from the per-row moments
  * With them the first Linear layer after the input LayerNorm is evaluated without materialising the rows
  * (dynamic-coverage-control_amd/algos/algo_utils/structured.py). */
 DCC_API int dcc_obs_features(dcc_env* env, int64_t n, const double* pos, const double* vel, const float* energy,
-                             const uint8_t* done, float* head, float* poi_feat, double* stats, void* stream);
+                             const uint8_t* done, float* head, float* poi_feat, double* stats, double* cstats,
+                             void* stream);
 
 /* Algorithmic HBM bytes of one env-step (SURVEY.md section 8d, fp32 I/O contract):
  * 40N + 11M + 11 + 4*N*D; with_actions=0 drops 8N; with_obs=0 drops 4*N*D. */

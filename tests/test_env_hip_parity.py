@@ -425,6 +425,11 @@ def test_obs_features_match_the_rows(N, M):
     assert torch.equal(f["head"], ref["head"]) and torch.equal(f["poi_feat"], ref["poi_feat"])
     np.testing.assert_allclose(f["stats"][..., 0].cpu().numpy(), ref["stats"][..., 0].cpu().numpy(), rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(f["stats"][..., 1].cpu().numpy(), ref["stats"][..., 1].cpu().numpy(), rtol=1e-11)
+    # pooled moments of the centralised row (N rows concatenated) == moments computed on the concatenation
+    np.testing.assert_allclose(f["cstats"][:, 0].cpu().numpy(), ref["cstats"][:, 0].cpu().numpy(), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(f["cstats"][:, 1].cpu().numpy(), ref["cstats"][:, 1].cpu().numpy(), rtol=1e-10)
+    only_c = env.obs_features(*st, out=dict(cstats=torch.empty(K * E, 2, dtype=torch.float64, device=env.device)))
+    assert torch.equal(only_c["cstats"], f["cstats"])
     # partial outputs
     only = env.obs_features(*st, out=dict(stats=torch.empty(K * E, N, 2, dtype=torch.float64, device=env.device)))
     assert torch.equal(only["stats"], f["stats"])
