@@ -109,6 +109,12 @@ class Learner:
         self.start_iter, self.cur_iter = 1, 0
         self._graphs = {}
         self.use_hip_graph = bool(self.cfg.use_hip_graph) and ptu.device.type == "cuda"
+        if self.use_hip_graph and self.train_envs.n_envs > 32768:
+            # the rollout's torch reductions run over the E per-env rewards; multi-block reductions inside a replayed
+            # graph are not reliable on this stack (tools/graph_reduce_probe.py: wrong from 131 k elements, fine at 32 k)
+            if self.rank == 0:
+                print("use_hip_graph disabled: %d envs per GPU exceeds the verified range" % self.train_envs.n_envs)
+            self.use_hip_graph = False
 
     def _make_buffer(self, envs):
         bcfg = copy.deepcopy(self.cfg)

@@ -336,13 +336,15 @@ def test_structured_learner_full_train_loop_with_eval_envs(tmp_path):
 
 
 def test_graph_replayed_ppo_epochs_equal_eager_epochs():
-    """use_hip_graph_update: the captured epoch (forward, backward, clip, capturable Adam with a device lr) replayed
-    N times == the same epochs issued eagerly -- parameters, ValueNorm and metrics bit for bit, across an LR decay."""
+    """use_hip_graph_update (experimental, off by default): the captured epoch (forward, backward, clip, capturable Adam
+    with a device lr) replayed a few times == the same epochs issued eagerly -- parameters, ValueNorm and metrics bit
+    for bit, across an LR decay.  (Long runs are NOT safe on this stack: tools/graph_reduce_probe.py.)"""
     import utils.pytorch_utils as ptu
     ptu.set_gpu_mode(True, 0)
     from learner import Learner
     kw = dict(n_rollout_threads=24, n_eval_rollout_threads=0, num_agents=4, num_pois=20, max_ep_len=20, n_iters=3,
               ppo_epoch=4, algo_hidden_size=64, save_model=False, seed=13)
+    kw["use_hip_graph_update"] = True                  # opt-in (experimental, see algos/mappo.py)
     g = Learner(_cfg(**kw))
     e = Learner(_cfg(**kw))
     e.trainer.graph_update = False                     # same capturable optimizers, epochs issued eagerly
