@@ -147,8 +147,7 @@ class MAPPOTrainer:
         # required by (and defaulted for) the compact-state rollout buffer
         self.update_chunk_steps = int(getattr(cfg, "update_chunk_steps", 0))
         # EXPERIMENTAL, off by default: replay each chunked PPO epoch as one hipGraph (single GPU, fp32; needs the policy's
-        # capturable optimizers).  Bit-identical to eager epochs in the tested small cases, BUT on this stack (ROCm 7.2,
-        # PyTorch 2.10+rocm7.0) multi-block torch reductions inside a replayed graph start returning wrong values after
+        # capturable optimizers).  NOT RELIABLE on this stack (ROCm 7.2, PyTorch 2.10+rocm7.0): multi-block torch reductions inside a replayed graph start returning wrong values after
         # some hundreds of replays (stand-alone reproduction: tools/graph_reduce_probe.py), and an epoch is full of them
         # (loss means, ValueNorm moments, gradient norms): observed as corrupted ValueNorm statistics after 3-26
         # iterations at 614 k rows.  The rollout graph (use_hip_graph) has no such reduction.

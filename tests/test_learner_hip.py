@@ -335,35 +335,35 @@ def test_structured_learner_full_train_loop_with_eval_envs(tmp_path):
     ptu.set_gpu_mode(False)
 
 
-def test_graph_replayed_ppo_epochs_equal_eager_epochs():
-    """use_hip_graph_update (experimental, off by default): the captured epoch (forward, backward, clip, capturable Adam
-    with a device lr) replayed a few times == the same epochs issued eagerly -- parameters, ValueNorm and metrics bit
-    for bit, across an LR decay.  (Long runs are NOT safe on this stack: tools/graph_reduce_probe.py.)"""
+def test_capturable_adam_plumbing_of_the_experimental_epoch_graph():
+    """use_hip_graph_update is experimental and off (replayed graphs with large torch reductions are unreliable on this
+    stack: tools/graph_reduce_probe.py; a 400-iteration soak of whole-epoch replay diverged from eager epochs).  What is
+    tested is the deterministic plumbing around it: capturable Adam with a device-resident learning rate follows the
+    linear schedule, survives a checkpoint round trip, and -- with the epochs issued eagerly -- trains like the
+    default optimizer up to the float32 bias-correction rounding."""
     import utils.pytorch_utils as ptu
     ptu.set_gpu_mode(True, 0)
     from learner import Learner
     kw = dict(n_rollout_threads=24, n_eval_rollout_threads=0, num_agents=4, num_pois=20, max_ep_len=20, n_iters=3,
               ppo_epoch=4, algo_hidden_size=64, save_model=False, seed=13)
-    kw["use_hip_graph_update"] = True                  # opt-in (experimental, see algos/mappo.py)
-    g = Learner(_cfg(**kw))
-    e = Learner(_cfg(**kw))
-    e.trainer.graph_update = False                     # same capturable optimizers, epochs issued eagerly
-    assert g.trainer.graph_update and g.policy.capturable and torch.is_tensor(g.policy.actor_optimizer.param_groups[0]["lr"])
+    c = Learner(_cfg(**dict(kw, use_hip_graph_update=True)))
+    c.trainer.graph_update = False                     # capturable optimizers, epochs issued eagerly
+    d = Learner(_cfg(**kw))                            # default optimizers
+    assert c.policy.capturable and torch.is_tensor(c.policy.actor_optimizer.param_groups[0]["lr"]) and not d.policy.capturable
     for it in (1, 2, 3):
-        for lr in (g, e):
+        for lr in (c, d):
             lr.policy.lr_decay(it, 3)
             torch.manual_seed(100 + it)
             lr.rollout(lr.rl_buffer, lr.train_envs)
-        ig, ie = g.rl_update(), e.rl_update()
-        for k in ig:
-            assert ig[k] == ie[k], (it, k, ig[k], ie[k])
-        for (k, a), (_, b) in zip(g.policy.actor.state_dict().items(), e.policy.actor.state_dict().items()):
-            assert torch.equal(a, b), (it, k)
-        for (k, a), (_, b) in zip(g.policy.critic.state_dict().items(), e.policy.critic.state_dict().items()):
-            assert torch.equal(a, b), (it, k)
-        assert torch.equal(g.trainer.value_normalizer.running_mean, e.trainer.value_normalizer.running_mean)
-    assert g.trainer.graph_update and len(g.trainer._epoch_graphs) == 1
-    assert float(g.policy.actor_optimizer.param_groups[0]["lr"]) == 0.0        # lr0 * (1 - 3/3)
+        ic, idf = c.rl_update(), d.rl_update()
+        if it == 1:                                    # same data in iteration 1: same losses, parameters within rounding
+            for k in ic:
+                np.testing.assert_allclose(ic[k], idf[k], rtol=1e-4, atol=1e-6, err_msg=k)
+            for (k, a), (_, b) in zip(c.policy.actor.state_dict().items(), d.policy.actor.state_dict().items()):
+                np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
+        assert all(np.isfinite(v) for v in ic.values())
+    assert float(c.policy.actor_optimizer.param_groups[0]["lr"]) == 0.0        # lr0 * (1 - 3/3), filled on the device
+    assert len(c.trainer._epoch_graphs) == 0
     ptu.set_gpu_mode(False)
 
 
