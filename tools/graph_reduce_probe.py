@@ -1,7 +1,12 @@
 """Stand-alone PyTorch-only probe (no code of this repo): large multi-block reductions inside a captured-and-replayed
 hipGraph return wrong values on this stack (ROCm 7.2 / PyTorch 2.10+rocm7.0, MI355X) after a few replays.
 This is why `use_hip_graph_update` (replaying whole PPO epochs, which are full of such reductions) is off by default;
-the rollout graph (`use_hip_graph`) contains no multi-block torch reduction and is verified bit-identical to eager."""
+the rollout graph (`use_hip_graph`) contains no multi-block torch reduction and is verified bit-identical to eager
+(tools/graph_rollout_soak.py).  Observations: every full-tensor reduction flavour (sum, mean, vector_norm, mean of squares) of
+>= 131 k elements fails, from the same replay index on (~815 with 24 reductions per replay) and then persistently; row-wise
+reductions ([600, 1024].sum(1)) and reductions of <= 32 k elements never do; a single such reduction per replay with changing
+inputs is right for the first replays -- i.e. the semaphore-reset memset of PyTorch's multi-block reduce is executed at first,
+and something in the replay machinery gives out after some tens of thousands of replayed nodes of that kind."""
 import sys
 import torch
 
