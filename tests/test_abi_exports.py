@@ -100,3 +100,18 @@ def test_mlp_entry_points_validate_before_touching_the_device():
     assert L.dcc_actor_l1_bwd(p, p, None, p, p, p, p, p, 1e-5, 1e-5, 90, p, None, None, p, p, p, p, p, 1, 4, 10, 8, None) == -1
     assert L.dcc_ppo_policy_loss(p, p, p, p, p, None, 0.2, p, p, p, 16, 5, 2, None) == -4   # more than 4 action dims
     assert L.dcc_ppo_policy_loss(p, p, p, p, p, None, 0.2, None, p, p, 16, 2, 2, None) == -1
+
+
+def test_headers_are_plain_c():
+    """include/*.h must be consumable from C (the boundary is a C ABI): a C99 translation unit including all of them."""
+    import subprocess, tempfile
+    hdrs = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+    assert len(hdrs) >= 3
+    with tempfile.NamedTemporaryFile("w", suffix=".c", delete=False) as f:
+        for h in hdrs:
+            f.write('#include "%s"\n' % os.path.basename(h))
+        f.write("int main(void) { return dcc_abi_version(); }\n")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I",
+                        os.path.join(ROOT, "include"), f.name], capture_output=True, text=True)
+    os.unlink(f.name)
+    assert r.returncode == 0, r.stderr
