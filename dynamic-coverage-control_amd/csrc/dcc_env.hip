@@ -994,6 +994,147 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
     }
 }
 
+// ---- kernel 5: split -- one env per workgroup: a physics wave + kSplitObs observation waves (M > 64) ------------
+// The BASELINE shards with many PoIs per env are small in env count (c4: 1024 envs per GPU, c5: 2048), so the fused
+// kernel runs one wave per SIMD: nothing hides the latency of its 84 KB (c4) of row stores per step, and physics and
+// stores alternate instead of overlapping.  Here the rows of an env are produced by kSplitObs waves in parallel (each a
+// contiguous, float4-aligned range of agent rows with its own staging window) while the physics wave is already on
+// the next step; the hand-off is the double-buffered LDS slot of the role-specialised kernel, sized for any M.
+constexpr int kSplitObs = 3;
+constexpr int kSplitBlock = 64 * (1 + kSplitObs);
+struct SplitSlot { double2* apos; double2* avel; float* en; unsigned* dm; };
+__device__ __forceinline__ int split_slot_bytes(int N, int ppl) { return N * 32 + ppl * 256 + 256; }
+__device__ __forceinline__ SplitSlot split_slot_at(unsigned char* base, int N, int ppl) {
+    SplitSlot h;
+    h.apos = reinterpret_cast<double2*>(base);
+    h.avel = h.apos + N;                                   // contiguous with apos: produce_obs indexes both through one pointer
+    h.en = reinterpret_cast<float*>(h.avel + N);
+    h.dm = reinterpret_cast<unsigned*>(h.en + ppl * 64);
+    return h;
+}
+
+// produce_obs() restricted to the agent rows [i0, i1): the stream of `st` starts at row i0.
+template <int PPL, bool FORCE, int NC, int MC>
+__device__ __forceinline__ void produce_obs_rows(const KParams& p, Stager& st, const double* apv, const float (&en)[PPL],
+                                                 const unsigned dmask, const PoiLane<PPL>& poi, const int lane,
+                                                 const int i0, const int i1) {
+    constexpr bool SPEC = NC > 0;
+    const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
+    const int H = 4 + 2 * (N - 1), D = H + 5 * M;
+    const double2* apos = reinterpret_cast<const double2*>(apv);
+    for (int i = i0; i < i1; ++i) {
+        const double2 xi = apos[i];
+        const int rb = (i - i0) * D;
+        for (int f0 = 0; f0 < H; f0 += 64) {
+            const int len = (H - f0) < 64 ? (H - f0) : 64;
+            float* dst = st.reserve(rb + f0, len, lane);
+            const int f = f0 + lane;
+            if (f < H) {
+                const int c = f & 1;
+                const int kk = (f - 4) >> 1;
+                const bool rel = f >= 4;
+                const int src = rel ? (kk + (kk >= i ? 1 : 0)) : (f < 2 ? N + i : i);
+                const double val = apv[2 * src + c];
+                const double sub = rel ? (c ? xi.y : xi.x) : 0.0;
+                dst[lane] = (float)(val - sub);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            if (q * 64 < M) {
+                const int cntj = (M - q * 64) < 64 ? (M - q * 64) : 64;
+                float* dst = st.reserve(rb + H + q * kTileFloats, 5 * cntj, lane);
+                if (lane < cntj) {
+                    float* d5 = dst + 5 * lane;
+                    const double2 pj = poi.get(q);
+                    d5[0] = (float)(pj.x - xi.x);
+                    d5[1] = (float)(pj.y - xi.y);
+                    d5[2] = en[q];
+                    d5[3] = p.m_energy_f;
+                    d5[4] = ((dmask >> q) & 1u) ? 1.f : 0.f;
+                }
+            }
+        }
+    }
+    st.flush((i1 - i0) * D, lane);
+}
+
+template <int PPL, int ACT, bool FORCE, int NC, int MC>
+__global__ __launch_bounds__(kSplitBlock, (PPL >= 8 || FORCE ? 1 : 2)) void dcc_env_split_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool SPEC = NC > 0;
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 = physics, 1.. = observation waves
+    const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
+    const int D = 4 + 2 * (N - 1) + 5 * M, L = N * D;
+    const int env = xcd_swizzle(blockIdx.x, gridDim.x);                  // grid = E: one env per workgroup
+
+    // LDS: PoI table | slot 0, slot 1 | flags: ready, consumed[kSplitObs] | kSplitObs staging windows
+    double2* s_poi = reinterpret_cast<double2*>(smem);
+    const int sb = split_slot_bytes(N, PPL);
+    unsigned char* hbase = smem + ((M * 16 + 15) & ~15);
+    unsigned* flags = reinterpret_cast<unsigned*>(hbase + 2 * sb);
+    float* stg_base = reinterpret_cast<float*>(hbase + 2 * sb + 16);
+
+    for (int j = threadIdx.x; j < M; j += kSplitBlock) s_poi[j] = p.poi[j];
+    if (threadIdx.x < 4) flags[threadIdx.x] = 0u;
+    __syncthreads();
+    PoiLane<PPL> poi;
+    poi.init(s_poi, lane, M);
+
+    if (role == 0) {
+        EnvRegs<PPL> r;
+        ActFetch<act_rf<PPL, FORCE>()> af;
+        init_act(af);
+        load_env_state<PPL>(p, env, lane, N, M, r);
+        {   // the "previous" slot (1) holds the pre-move positions of step 0
+            SplitSlot h = split_slot_at(hbase + sb, N, PPL);
+            if (lane < N) { h.apos[lane] = make_double2(r.px, r.py); h.avel[lane] = make_double2(r.vx, r.vy); }
+        }
+        wave_fence();
+        for (int k = 0; k < p.K; ++k) {
+            const int slot = k & 1;
+            SplitSlot out = split_slot_at(hbase + slot * sb, N, PPL);
+            SplitSlot in = split_slot_at(hbase + (slot ^ 1) * sb, N, PPL);
+            if (k >= 2) {   // slot `slot` was published at step k-2: every observation wave must have read it
+#pragma unroll
+                for (int w = 0; w < kSplitObs; ++w) spin_until_ge(&flags[1 + w], (unsigned)(k - 1));
+            }
+            env_physics_step<PPL, ACT, FORCE, NC, MC>(p, env, k, lane, r, af, poi, in.apos, out.apos, out.avel);
+            if (p.st_pos || p.st_vel || p.st_energy || p.st_done) write_step_state<PPL>(p, (size_t)k * p.E + env, lane, N, M, r);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) out.en[q * 64 + lane] = r.en[q];
+            out.dm[lane] = r.dmask;
+            publish(&flags[0], (unsigned)(k + 1), lane);
+        }
+        store_env_state<PPL>(p, env, lane, N, M, r);
+    } else {
+        __builtin_amdgcn_s_setprio(3);
+        const int w = role - 1;
+        const int vec = SPEC ? 1 : p.vec_ok;
+        // contiguous row ranges whose first float index i0 * D is a multiple of 4 in float4 mode
+        const int ra = vec ? ((D & 3) == 0 ? 1 : ((D & 1) == 0 ? 2 : 4)) : 1;
+        const int i0 = ((w * N) / kSplitObs) / ra * ra;
+        const int i1 = (w == kSplitObs - 1) ? N : (((w + 1) * N) / kSplitObs) / ra * ra;
+        float* stg = stg_base + w * kStageC;
+        for (int k = 0; k < p.K; ++k) {
+            spin_until_ge(&flags[0], (unsigned)(k + 1));
+            SplitSlot h = split_slot_at(hbase + (k & 1) * sb, N, PPL);
+            float en[PPL];
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) en[q] = h.en[q * 64 + lane];
+            const unsigned dmask = h.dm[lane];
+            if (i1 > i0) {
+                Stager st;
+                st.stg = stg; st.w0 = 0; st.vec = vec;
+                st.gout = p.obs + ((size_t)k * p.E + env) * (size_t)L + (size_t)i0 * D;
+                produce_obs_rows<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane, i0, i1);
+            }
+            publish(&flags[1 + w], (unsigned)(k + 1), lane);
+        }
+    }
+}
+
 // ================================ host side =====================================================
 
 thread_local std::string g_err;
@@ -1022,13 +1163,14 @@ struct dcc_env {
     double2* d_vel = nullptr;
     float* d_energy = nullptr;
     uint8_t* d_done = nullptr;
-    size_t lds_bytes = 0, lds_bytes_roles = 0;
-    bool no_spec = false, no_roles = false, force_roles = false;
+    size_t lds_bytes = 0, lds_bytes_roles = 0, lds_bytes_split = 0;
+    bool no_spec = false, no_roles = false, force_roles = false, no_split = false, force_split = false;
 };
 
 namespace {
 
 typedef void (*kernel_fn)(const KParams);
+constexpr int kSplitMaxEnvs = 3072;   // above this the fused kernel has >= 3 waves per SIMD of its own
 
 template <int ACT, bool FORCE>
 kernel_fn pick_ppl(int ppl) {
@@ -1082,6 +1224,23 @@ kernel_fn pick_roles_kernel(int act, bool force, int n, int m, bool allow_spec) 
                                                                           : pick_roles<2, false>(n, m, allow_spec);
 }
 
+// split kernels (several PoIs per lane): float32 / in-kernel actions, generic sizes + BASELINE config c4
+template <int ACT, bool FORCE>
+kernel_fn pick_split(int ppl, int n, int m, bool allow_spec) {
+    if (allow_spec && n == 16 && m == 256) return dcc_env_split_kernel<4, ACT, FORCE, 16, 256>;
+    switch (ppl) {
+        case 2: return dcc_env_split_kernel<2, ACT, FORCE, 0, 0>;
+        case 4: return dcc_env_split_kernel<4, ACT, FORCE, 0, 0>;
+        case 8: return dcc_env_split_kernel<8, ACT, FORCE, 0, 0>;
+        default: return dcc_env_split_kernel<16, ACT, FORCE, 0, 0>;
+    }
+}
+
+kernel_fn pick_split_kernel(int ppl, int act, bool force, int n, int m, bool allow_spec) {
+    if (force) return act == 0 ? pick_split<0, true>(ppl, n, m, allow_spec) : pick_split<2, true>(ppl, n, m, allow_spec);
+    return act == 0 ? pick_split<0, false>(ppl, n, m, allow_spec) : pick_split<2, false>(ppl, n, m, allow_spec);
+}
+
 // act: 0 = f32 actions, 1 = f64 actions, 2 = in-kernel generator
 int launch(dcc_env* env, KParams& p, int act, void* stream) {
     // specialised kernels assume float4-aligned obs rows; DCC_NO_SPEC=1 forces the generic kernels (tests)
@@ -1096,6 +1255,20 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
         kernel_fn fn = pick_roles_kernel(act, p.use_force != 0, p.N, p.M, allow_spec);
         const int grid = (p.E + 1) / 2;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kRolesBlock), env->lds_bytes_roles, s, p);
+        HIP_TRY(hipGetLastError());
+        return DCC_OK;
+    }
+    // several PoIs per lane and few envs (the c4 / c5 shards): one env per workgroup, rows produced by kSplitObs waves
+    // while the physics wave runs ahead.  With many envs the fused kernel already fills the chip (c4 x 8192: 0.82 of
+    // peak) and stays the choice, and so it does for 16 PoIs per lane with the pull force on (c5: the single physics wave
+    // of a workgroup becomes the bottleneck: 398 vs 245 us/step).  Measured (us/step split vs fused, same box): 16 x 256 x
+    // 1024 envs 16.4 vs 19.8; 16 x 128 x 1024 9.2 vs 16.0; 9 x 500 x 1024 22.7 vs 27.9; 32 x 1024 x 2048 (no force) 232 vs
+    // 233.  DCC_NO_SPLIT=1 / DCC_FORCE_SPLIT=1: tests, A/B.
+    const bool split_pays = !(env->PPL >= 16 && p.use_force != 0);
+    if (p.obs != nullptr && env->PPL > 1 && act != 1 && p.mode == 0 && !env->no_split &&
+        ((p.K >= 2 && p.E <= kSplitMaxEnvs && split_pays) || env->force_split)) {
+        kernel_fn fn = pick_split_kernel(env->PPL, act, p.use_force != 0, p.N, p.M, allow_spec);
+        hipLaunchKernelGGL(fn, dim3(p.E), dim3(kSplitBlock), env->lds_bytes_split, s, p);
         HIP_TRY(hipGetLastError());
         return DCC_OK;
     }
@@ -1240,8 +1413,12 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     { const char* ns = std::getenv("DCC_NO_SPEC"); e->no_spec = ns && ns[0] == '1'; }
     { const char* nr = std::getenv("DCC_NO_ROLES"); e->no_roles = nr && nr[0] == '1'; }
     { const char* fr = std::getenv("DCC_FORCE_ROLES"); e->force_roles = fr && fr[0] == '1'; }
+    { const char* ns = std::getenv("DCC_NO_SPLIT"); e->no_split = ns && ns[0] == '1'; }
+    { const char* fs = std::getenv("DCC_FORCE_SPLIT"); e->force_split = fs && fs[0] == '1'; }
     e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kStageC * 4;
     e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);
+    e->lds_bytes_split = (size_t)((M * 16 + 15) & ~15) + 2 * ((size_t)N * 32 + (size_t)p2 * 256 + 256) + 16 +
+                         (size_t)kSplitObs * kStageC * 4;
 
     auto cleanup = [&](int code, const std::string& m) { dcc_env_destroy(e); return fail(code, m); };
     hipError_t err;

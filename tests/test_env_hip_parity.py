@@ -31,19 +31,21 @@ def _mk(c, z, E=None):
 @pytest.mark.parametrize("path", golden_env_files(), ids=lambda p: os.path.basename(p)[4:-4])
 def test_hip_step_matches_reference_golden(path, variant, monkeypatch):
     """Every kernel family must reproduce the reference: compile-time (N, M) specialisations vs the generic
-    runtime-size code (DCC_NO_SPEC=1), and the role-specialised physics/observation-wave kernel vs the fused
-    one-wave-per-env kernel (DCC_NO_ROLES=1)."""
+    runtime-size code (DCC_NO_SPEC=1), and the multi-wave kernels -- role-specialised physics/observation waves
+    (M <= 64) or the split kernel with one physics and three observation waves per env (M > 64) -- vs the fused
+    one-wave-per-env kernel (DCC_NO_ROLES=1 / DCC_NO_SPLIT=1)."""
     z, c = load_case(path)
     spec, roles = variant.split("-")
     has_spec = (c["N"], c["M"]) in ((8, 64), (4, 16), (4, 20), (16, 256))
-    has_roles = c["M"] <= 64
     if spec == "generic" and not has_spec:
         pytest.skip("no specialised kernel for this size: the generic path is what 'spec' already ran")
-    if roles == "fused" and not has_roles:
-        pytest.skip("more than one PoI per lane: only the fused kernel exists, 'roles' already ran it")
+    if roles == "roles" and c["M"] > 64 and not c["act_f32"]:
+        pytest.skip("the split kernel takes float32 / in-kernel actions; float64 actions use the fused kernel")
     monkeypatch.setenv("DCC_NO_SPEC", "1" if spec == "generic" else "0")
     monkeypatch.setenv("DCC_NO_ROLES", "1" if roles == "fused" else "0")
     monkeypatch.setenv("DCC_FORCE_ROLES", "1" if roles == "roles" else "0")   # single-step launches default to fused
+    monkeypatch.setenv("DCC_NO_SPLIT", "1" if roles == "fused" else "0")
+    monkeypatch.setenv("DCC_FORCE_SPLIT", "1" if roles == "roles" else "0")
     env = _mk(c, z)
     dev = env.device
     obs0 = env.reset()
@@ -88,8 +90,12 @@ def test_hip_step_matches_reference_golden(path, variant, monkeypatch):
 @pytest.mark.parametrize("N,M,cfs,r_comm", [(8, 64, 0.0, 0.4), (8, 64, 0.5, 0.2), (5, 37, 0.5, 0.3), (16, 256, 0.5, 0.15),
                                             (32, 1024, 0.5, 0.1), (3, 130, 1.0, 0.3), (64, 70, 0.5, 0.08),
                                             (64, 1024, 0.5, 0.05), (1, 1, 0.0, 0.4), (2, 64, 1.0, 0.3), (9, 500, 0.0, 0.2)])
-def test_hip_step_matches_oracle_random(N, M, cfs, r_comm, oracle_mod):
-    """Seeded random actions, E=33 envs (not a multiple of the 4 envs per workgroup), 40 steps."""
+@pytest.mark.parametrize("multi_wave", [False, True])
+def test_hip_step_matches_oracle_random(N, M, cfs, r_comm, multi_wave, oracle_mod, monkeypatch):
+    """Seeded random actions, E=33 envs (not a multiple of the 4 envs per workgroup), 40 steps; with the fused kernel
+    and with the multi-wave kernel of the size (roles for M <= 64, split for M > 64) forced for the single-step launches."""
+    monkeypatch.setenv("DCC_FORCE_ROLES", "1" if multi_wave else "0")
+    monkeypatch.setenv("DCC_FORCE_SPLIT", "1" if multi_wave else "0")
     E, T = (33, 40) if N * M < 20000 else (5, 12)
     rs = np.random.RandomState(N * 1000 + M)
     poi = rs.uniform(-1, 1, (M, 2))
