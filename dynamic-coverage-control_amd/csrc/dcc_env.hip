@@ -1266,7 +1266,7 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
     // 233.  DCC_NO_SPLIT=1 / DCC_FORCE_SPLIT=1: tests, A/B.
     const bool split_pays = !(env->PPL >= 16 && p.use_force != 0);
     if (p.obs != nullptr && env->PPL > 1 && act != 1 && p.mode == 0 && !env->no_split &&
-        ((p.K >= 2 && p.E <= kSplitMaxEnvs && split_pays) || env->force_split)) {
+        ((p.E <= kSplitMaxEnvs && split_pays) || env->force_split)) {   // single steps too: 24.8 -> 22.2 us at the c4 shard
         kernel_fn fn = pick_split_kernel(env->PPL, act, p.use_force != 0, p.N, p.M, allow_spec);
         hipLaunchKernelGGL(fn, dim3(p.E), dim3(kSplitBlock), env->lds_bytes_split, s, p);
         HIP_TRY(hipGetLastError());

@@ -1,8 +1,9 @@
-"""Host-side cost of one HipCoverageEnv.step() call (Python + ctypes + launch), and the GPU time per single-step launch."""
+"""Host-side cost of one HipCoverageEnv.step() call (Python + ctypes + launch), and the GPU time per single-step launch.
+usage: python tools/step_overhead.py [E N M]"""
 import os, sys, time
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, R + "/dynamic-coverage-control_amd")
 import numpy as np, torch, dcc_hip
-E, N, M = 4096, 8, 64
+E, N, M = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (4096, 8, 64)
 poi = np.load(R + "/dynamic-coverage-control_amd/envs/mpe/pos_pois.npy")[:M]
 env = dcc_hip.HipCoverageEnv(E, N, M, poi)
 env.reset()
