@@ -41,12 +41,14 @@ def init_distributed(backend=None):
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:   # DCC_DIST_BACKEND=gloo is a test hook: the ranks may then share one GPU (gloo moves CUDA tensors)
+        backend = os.environ.get("DCC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         set_gpu_mode(True, int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
     else:
+        if torch.cuda.is_available():
+            set_gpu_mode(True, int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world
 
