@@ -186,3 +186,37 @@ def policy_loss_usable(mean, old_logp):
 def policy_loss(mean, logstd, actions, old_logp, adv, active, clip, use_active):
     """(policy_loss, dist_entropy, ratio_mean) of mappo.py:150-160 / act.py:165-179 from the Gaussian mean."""
     return _PolicyLoss.apply(mean, logstd, actions, old_logp, adv, active, float(clip), bool(use_active))
+
+
+class _ValueLoss(torch.autograd.Function):
+    """Clipped Huber / MSE value loss from the per-env critic output in one HIP pass (dcc_ppo_value_loss)."""
+
+    @staticmethod
+    def forward(ctx, values, value_preds, returns, active, norm, clip, delta, use_clipped, use_masks, n_agents):
+        import dcc_hip
+        n = values.numel()
+        R = n * n_agents
+        act = active.reshape(R).contiguous() if (use_masks and active is not None) else None
+        dv_raw, sums = dcc_hip.ppo_value_loss(values.reshape(n).contiguous(), value_preds.reshape(R).contiguous(),
+                                              returns.reshape(R).contiguous(), act, norm, clip, delta, use_clipped, n_agents)
+        denom = sums[1] if act is not None else torch.full((), float(R), device=values.device)
+        ctx.save_for_backward(dv_raw, denom)
+        ctx.shape = values.shape
+        return sums[0] / denom
+
+    @staticmethod
+    def backward(ctx, g):
+        dv_raw, denom = ctx.saved_tensors
+        return (dv_raw * (g / denom)).view(ctx.shape), None, None, None, None, None, None, None, None, None
+
+
+def value_loss_usable(values):
+    return ENABLED and values.is_cuda and values.dtype == torch.float32 and not torch.is_autocast_enabled()
+
+
+def value_loss(values, value_preds, returns, active, norm, clip, huber_delta, use_clipped, use_masks, n_agents):
+    """mappo.py:103-131 on [n] critic outputs shared by n_agents rows each; norm = ValueNorm's {mean, std} tensor or None;
+    huber_delta None = MSE."""
+    return _ValueLoss.apply(values, value_preds, returns, active, norm, float(clip),
+                            float(huber_delta) if huber_delta is not None else -1.0, bool(use_clipped), bool(use_masks),
+                            int(n_agents))

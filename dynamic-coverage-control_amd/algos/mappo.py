@@ -208,8 +208,10 @@ class MAPPOTrainer:
                     prenormalized=prenormalized)
             values = self.policy.critic(share_obs_batch, prenormalized=prenormalized)[0]
         values = values.float()
-        if values.shape[0] != n_rows:
-            n_rep = n_rows // values.shape[0]
+        n_rep = n_rows // values.shape[0]
+        fused_vloss = (not self.amp_bf16 and ptu.device.type == "cuda" and fused.value_loss_usable(values)
+                       and values.shape[0] * n_rep == n_rows)
+        if values.shape[0] != n_rows and not fused_vloss:
             values = values.unsqueeze(1).expand(-1, n_rep, -1).reshape(-1, 1)
 
         if fused_loss:
@@ -226,7 +228,17 @@ class MAPPOTrainer:
                 policy_loss = (-surr * active_masks_batch).sum() / active_masks_batch.sum()
             else:
                 policy_loss = -surr.mean()
-        value_loss = self.cal_value_loss(values, value_preds_batch, return_batch, active_masks_batch, update_norm)
+        if fused_vloss:     # clipped Huber loss and its gradient from the per-env values in one HIP pass (dcc_ppo_value_loss)
+            norm = None
+            if self._use_valuenorm:
+                if update_norm:
+                    self.value_normalizer.update(return_batch)
+                norm = self.value_normalizer.denorm_params()          # {mean, std}: normalize(x) = (x - mean) / std
+            value_loss = fused.value_loss(values, value_preds_batch, return_batch, active_masks_batch, norm, self.clip_param,
+                                          self.huber_delta if self._use_huber_loss else None, self._use_clipped_value_loss,
+                                          self._use_value_active_masks, n_rep)
+        else:
+            value_loss = self.cal_value_loss(values, value_preds_batch, return_batch, active_masks_batch, update_norm)
         return policy_loss, dist_entropy, value_loss, imp_weights
 
     def _optimizer_step(self):

@@ -458,6 +458,67 @@ __global__ __launch_bounds__(kBlock) void ppo_policy_loss_k(const float* __restr
     }
 }
 
+// ---- clipped value loss (Huber / MSE) of the centralised critic, forward and gradient in one pass ----------------------
+// One thread per critic row e (one value for the N agents of an env-step); per agent row r = e*N + i:
+//   target = (ret - mean) / std (ValueNorm) or ret;  vpc = vp + clamp(v - vp, -clip, clip)
+//   loss = max(h(target - v), h(target - vpc))   with the reference's ONE-SIDED Huber h (utils/util.py:36-39) or e^2/2
+// PyTorch gradient conventions (maximum splits ties evenly, clamp passes the gradient on the closed interval).
+__device__ __forceinline__ float vl_h(float e, float d, bool huber) {
+    if (!huber) return e * e * 0.5f;
+    const float a = fabsf(e) <= d ? 1.f : 0.f, b = e > d ? 1.f : 0.f;
+    return a * e * e * 0.5f + b * d * (fabsf(e) - d * 0.5f);
+}
+__device__ __forceinline__ float vl_dh(float e, float d, bool huber) {
+    if (!huber) return e;
+    return (fabsf(e) <= d ? e : 0.f) + (e > d ? d : 0.f);
+}
+__global__ __launch_bounds__(kBlock) void ppo_value_loss_k(const float* __restrict__ values, const float* __restrict__ vpred,
+                                                           const float* __restrict__ returns, const float* __restrict__ active,
+                                                           const float* __restrict__ norm, float clip, float delta,
+                                                           int use_clipped, float* __restrict__ dvalues,
+                                                           float* __restrict__ ws, long long n, int N) {
+    __shared__ float red[kWavesPerBlock][2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const bool huber = delta > 0.f;
+    float mean = 0.f, sd = 1.f;
+    if (norm) { mean = norm[0]; sd = norm[1]; }
+    float acc_l = 0.f, acc_a = 0.f;
+    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < n; e += (long long)gridDim.x * kBlock) {
+        const float v = values[e];
+        float dv = 0.f;
+        for (int i = 0; i < N; ++i) {
+            const long long r = e * N + i;
+            const float vp = vpred[r];
+            const float target = norm ? (returns[r] - mean) / sd : returns[r];
+            const float act = active ? active[r] : 1.f;
+            const float dlt = v - vp;
+            const float vpc = vp + fminf(fmaxf(dlt, -clip), clip);
+            const float eo = target - v, ec = target - vpc;
+            const float lo = vl_h(eo, delta, huber), lc = vl_h(ec, delta, huber);
+            const float go = -vl_dh(eo, delta, huber);                                        // d lo / d v
+            const float gc = (dlt >= -clip && dlt <= clip) ? -vl_dh(ec, delta, huber) : 0.f;  // d lc / d v
+            float l = lo, g = go;
+            if (use_clipped) {
+                l = fmaxf(lo, lc);
+                g = lo > lc ? go : (lo < lc ? gc : 0.5f * (go + gc));
+            }
+            acc_l += l * act;
+            acc_a += act;
+            dv += g * act;
+        }
+        dvalues[e] = dv;
+    }
+    const float tl = wave_sum(acc_l), ta = wave_sum(acc_a);
+    if (lane == 0) { red[wid][0] = tl; red[wid][1] = ta; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        float t = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < kWavesPerBlock; ++w2) t += red[w2][threadIdx.x];
+        ws[(long long)blockIdx.x * 2 + threadIdx.x] = t;
+    }
+}
+
 // ---- rollout glue: sample + log-prob + buffer insert in one launch, reward / mask record in another -------------------
 // (Learner.collect / insert, learner.py:227-276: ~18 element-wise launches per env step otherwise.)
 __global__ __launch_bounds__(kBlock) void rollout_sample_k(const float* __restrict__ mean, const float* __restrict__ logstd,
@@ -903,6 +964,20 @@ DCC_API int dcc_ppo_policy_loss(const float* mean, const float* logstd, const fl
                        active, clip, dmean, workspace, (long long)R, (int)A, (int)K);
     const long long nseg = reduce_stage1(workspace, blocks, kPpoP, kPpoP, st_);
     hipLaunchKernelGGL(reduce_partials_k, dim3(1), dim3(kBlock), 0, st_, workspace, nseg, kPpoP, kSegWaves * kPpoP, sums);
+    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+}
+
+DCC_API int dcc_ppo_value_loss(const float* values, const float* value_preds, const float* returns, const float* active,
+                               const float* norm, float clip, float delta, int32_t use_clipped, float* dvalues, float* sums,
+                               float* workspace, int64_t n, int32_t N, void* stream) {
+    if (!values || !value_preds || !returns || !dvalues || !sums || !workspace || n < 1 || N < 1) return kEINVAL;
+    hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
+    long long blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > kReluLnBlocks * 2) blocks = kReluLnBlocks * 2;
+    hipLaunchKernelGGL(ppo_value_loss_k, dim3((unsigned)blocks), dim3(kBlock), 0, st_, values, value_preds, returns, active,
+                       norm, clip, delta, (int)use_clipped, dvalues, workspace, (long long)n, (int)N);
+    const long long nseg = reduce_stage1(workspace, blocks, 2, 2, st_);
+    hipLaunchKernelGGL(reduce_partials_k, dim3(1), dim3(kBlock), 0, st_, workspace, nseg, 2, kSegWaves * 2, sums);
     return hipGetLastError() == hipSuccess ? 0 : kEHIP;
 }
 

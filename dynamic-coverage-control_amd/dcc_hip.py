@@ -44,7 +44,7 @@ EXPORTS = ["dcc_obs_expand", "dcc_gae_compute", "dcc_abi_version", "dcc_last_err
            "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout", "dcc_env_get_state",
            "dcc_env_set_state", "dcc_env_bytes_per_step", "dcc_obs_features",
            "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_relu_ln_head_fwd", "dcc_relu_ln_head_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd", "dcc_ppo_policy_loss",
-           "dcc_rollout_sample", "dcc_rollout_record"]
+           "dcc_rollout_sample", "dcc_rollout_record", "dcc_ppo_value_loss"]
 
 _lib = None
 
@@ -84,6 +84,7 @@ def load_library(path=None):
     L.dcc_relu_ln_head_fwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, _vp, _vp, i64, i32, i32, _vp]
     L.dcc_relu_ln_head_bwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, _vp, _vp, _vp, _vp, i64, i32, i32, _vp]
     L.dcc_ppo_policy_loss.argtypes = [_vp] * 6 + [f32, _vp, _vp, _vp, i64, i32, i32, _vp]
+    L.dcc_ppo_value_loss.argtypes = [_vp] * 5 + [f32, f32, i32, _vp, _vp, _vp, i64, i32, _vp]
     L.dcc_rollout_sample.argtypes = [_vp] * 7 + [i64, i32, i32, i32, _vp]
     L.dcc_rollout_record.argtypes = [_vp] * 4 + [i64, i32, _vp]
     L.dcc_mlp_workspace_floats.argtypes = [i32, i32]
@@ -413,6 +414,21 @@ def ppo_policy_loss(mean, logstd, actions, old_logp, adv, active, clip):
                                                   _ptr(None if active is None else _f32c(active, "active")), clip, _ptr(dmean),
                                                   _ptr(sums), _ptr(ws), R, A, K, _stream()), "dcc_ppo_policy_loss")
     return dmean, sums
+
+
+def ppo_value_loss(values, value_preds, returns, active, norm, clip, delta, use_clipped, n_agents):
+    """-> dvalues_raw [n], sums [2] (include/dcc_mlp.h: dcc_ppo_value_loss)."""
+    n = values.numel()
+    dev = values.device
+    dv = torch.empty(n, dtype=torch.float32, device=dev)
+    sums = torch.empty(2, dtype=torch.float32, device=dev)
+    ws = torch.empty(2 * 2048, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load_library().dcc_ppo_value_loss(_ptr(_f32c(values, "values")), _ptr(_f32c(value_preds, "value_preds")),
+                                                 _ptr(_f32c(returns, "returns")), _ptr(None if active is None else _f32c(active, "active")),
+                                                 _ptr(None if norm is None else _f32c(norm, "norm")), clip, delta, int(use_clipped),
+                                                 _ptr(dv), _ptr(sums), _ptr(ws), n, n_agents, _stream()), "dcc_ppo_value_loss")
+    return dv, sums
 
 
 def rollout_sample(mean, logstd, eps, value, actions_out, logp_out, value_preds_out, n_agents):

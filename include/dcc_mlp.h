@@ -82,6 +82,19 @@ DCC_API int dcc_ppo_policy_loss(const float* mean, const float* logstd, const fl
                                 float* workspace, int64_t R, int32_t A, int32_t K, void* stream);
 
 /*
+ * Clipped value loss of the centralised critic (MAPPOTrainer.cal_value_loss, algos/mappo.py:103-131, with the one-sided
+ * Huber of utils/util.py:36-39 when delta > 0, e^2/2 when delta <= 0), value and gradient in one pass:
+ *   values [n]: one critic output per env-step, shared by its N agent rows r = e*N + i;  value_preds, returns, active [n*N]
+ *   (active may be NULL = all ones);  norm = {mean, std} of ValueNorm (utils/valuenorm.py:57-66) or NULL
+ *   loss_r = max(h(target_r - v_e), h(target_r - (vp_r + clamp(v_e - vp_r, -clip, clip))))  (use_clipped = 0: first term only)
+ * Outputs: dvalues [n] = d(sum_r active_r loss_r)/d values;  sums [2] = {sum_r active_r loss_r, sum_r active_r}.
+ * workspace: >= 2 * 2048 floats.
+ */
+DCC_API int dcc_ppo_value_loss(const float* values, const float* value_preds, const float* returns, const float* active,
+                               const float* norm, float clip, float delta, int32_t use_clipped, float* dvalues, float* sums,
+                               float* workspace, int64_t n, int32_t N, void* stream);
+
+/*
  * Rollout glue (Learner.collect / insert, learner.py:227-276; SharedReplayBuffer.insert, buffer/shared_buffer.py:72-105).
  * dcc_rollout_sample: actions = mean + exp(logstd) * eps (FixedNormal.sample), logp = sum_d Normal.log_prob (written to
  *   all K columns of the buffer's [R,K] log-prob slot), value_preds[r] = value[r / N] (one critic value per env broadcast

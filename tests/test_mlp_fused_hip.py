@@ -272,3 +272,43 @@ def test_fused_policy_loss_matches_autograd(R, A, K, masked):
         _close(a, b, name, rtol=2e-5, atol=2e-6)
     f2 = run(True)
     assert all(torch.equal(a, b) for a, b in zip(f, f2))
+
+
+@pytest.mark.parametrize("n,N,huber,clipped,masked,normed", [(50001, 8, True, True, True, True), (3000, 4, False, True, False, True),
+                                                            (777, 1, True, False, True, False), (64, 16, True, True, False, False)])
+def test_fused_value_loss_matches_autograd(n, N, huber, clipped, masked, normed):
+    """dcc_ppo_value_loss == autograd on MAPPOTrainer.cal_value_loss (mappo.py:103-131) with the one-sided Huber: loss and
+    d/d values, errors on both sides of +-delta and of the clip range, partially inactive rows."""
+    from algos.algo_utils import fused
+    from utils.util import huber_loss, mse_loss
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(n + N)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    R = n * N
+    v0 = rnd(n, 1) * 6
+    vp = v0.repeat_interleave(N, 0) + rnd(R, 1) * 0.4                 # some |v - vp| above the clip of 0.2
+    ret = rnd(R, 1) * 300 - 200 if normed else v0.repeat_interleave(N, 0) + rnd(R, 1) * 14   # errors beyond +-10 too
+    active = (torch.rand(R, 1, device=dev, generator=g) > 0.25).float()
+    norm = torch.tensor([-190.0, 290.0], device=dev) if normed else None
+    clip, delta = 0.2, 10.0
+
+    def run(use_fused):
+        v = v0.clone().requires_grad_(True)
+        if use_fused:
+            loss = fused.value_loss(v, vp, ret, active, norm, clip, delta if huber else None, clipped, masked, N)
+        else:
+            vr = v.unsqueeze(1).expand(-1, N, -1).reshape(-1, 1)
+            vpc = vp + (vr - vp).clamp(-clip, clip)
+            target = (ret - norm[0]) / norm[1] if normed else ret
+            ec, eo = target - vpc, target - vr
+            lc, lo = (huber_loss(ec, delta), huber_loss(eo, delta)) if huber else (mse_loss(ec), mse_loss(eo))
+            l = torch.max(lo, lc) if clipped else lo
+            loss = (l * active).sum() / active.sum() if masked else l.mean()
+        loss.backward()
+        return loss.detach(), v.grad.clone()
+
+    f, t = run(True), run(False)
+    _close(f[0], t[0], "value_loss", rtol=2e-5, atol=1e-6)
+    _close(f[1], t[1], "dvalues", rtol=2e-5, atol=2e-6)
+    f2 = run(True)
+    assert torch.equal(f[0], f2[0]) and torch.equal(f[1], f2[1])
