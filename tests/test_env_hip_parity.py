@@ -89,7 +89,8 @@ def test_hip_step_matches_reference_golden(path, variant, monkeypatch):
 
 @pytest.mark.parametrize("N,M,cfs,r_comm", [(8, 64, 0.0, 0.4), (8, 64, 0.5, 0.2), (5, 37, 0.5, 0.3), (16, 256, 0.5, 0.15),
                                             (32, 1024, 0.5, 0.1), (3, 130, 1.0, 0.3), (64, 70, 0.5, 0.08),
-                                            (64, 1024, 0.5, 0.05), (1, 1, 0.0, 0.4), (2, 64, 1.0, 0.3), (9, 500, 0.0, 0.2)])
+                                            (64, 1024, 0.5, 0.05), (1, 1, 0.0, 0.4), (2, 64, 1.0, 0.3), (9, 500, 0.0, 0.2),
+                                            (1, 100, 0.0, 0.4), (2, 200, 1.0, 0.5), (7, 65, 0.5, 0.3)])
 @pytest.mark.parametrize("multi_wave", [False, True])
 def test_hip_step_matches_oracle_random(N, M, cfs, r_comm, multi_wave, oracle_mod, monkeypatch):
     """Seeded random actions, E=33 envs (not a multiple of the 4 envs per workgroup), 40 steps; with the fused kernel
