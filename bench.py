@@ -2,15 +2,22 @@
 """bench.py -- agent-env-steps/s of the batched coverage-env hot path on MI355X.
 
 Workload (BASELINE.json configs[1], "c2"): 8 UAVs x 64 PoIs x 4096 envs per GPU, random actions,
-env-step HIP kernel only.  A "step" is one batched env step over all E envs of every rank.  Steps
-are issued as fused launches of --steps-per-launch (default T=150, one rollout) env steps, each
-reading its actions [T,E,N,2] from HBM and writing obs [T,E,N,D] + per-step outputs to HBM, i.e.
-the full algorithmic byte contract of SURVEY.md section 8d (11,851 B per env-step at c2).
+env-step HIP kernel only.  A "step" (--steps K / --warmup W) is ONE PASS of the hot path over one
+batch of synthetic input: --launches-per-step (default 32) rollouts, each a fused launch of
+--steps-per-launch (default T=150) batched env steps over all E envs that reads its actions
+[T,E,N,2] from HBM and writes obs [T,E,N,D] + the per-step outputs to HBM, i.e. the full algorithmic
+byte contract of SURVEY.md section 8d (11,851 B per env-step at c2).  One step is therefore
+32 x 150 x 4096 x 8 = 157 M agent-env-steps and ~40 ms of GPU time, so the driver's
+`--steps 20 --warmup 5` times a 0.8 s region of 640 launches.
 
-  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      (N>1 without WORLD_SIZE in the environment: re-executes itself under torch.distributed.run, one rank per GPU)
 
-Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the launch stream;
-`cpu_baseline` times the CPU oracle (oracle/dcc_oracle.c, "port") on the host cores, rank 0, N=1.
+Prints ONE JSON line on rank 0.  `roofline` is always measured live: HIP events around every timed
+launch on the launch stream.  `cpu_baseline` times the CPU oracle (oracle/dcc_oracle.c, "port") on
+the host cores, rank 0, N=1.  `c3` (unless --no-c3) is a bounded run of BASELINE configs[2]: full
+MAPPO iterations (policy-driven rollout + HIP GAE + PPO epochs) at the same shape, with the RCCL
+gradient all-reduce when N>1; it never affects `value`.
 """
 import argparse
 import json
@@ -94,26 +101,24 @@ def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, budget_s=10.0):
             "value_1core": rate1}
 
 
-def bench_mappo(args):
-    """BASELINE config 3: 8 UAV x 64 PoI x 4096 envs per GPU, T=150 policy-driven env steps, HIP GAE scan and
-    ppo_epoch full-batch PPO epochs per iteration (fp32, critic evaluated once per env).  Not the headline."""
+def mappo_iterations(args, iters, warm_iters=2):
+    """BASELINE config 3: N UAV x M PoI x E envs per GPU, T policy-driven env steps, HIP GAE scan and ppo_epoch
+    full-batch PPO epochs per iteration (fp32, critic evaluated once per env).  Returns the measurement dict."""
     import yaml
     from argparse import Namespace
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import utils.pytorch_utils as ptu
-    ptu.set_gpu_mode(True, local_rank)
+    ptu.set_gpu_mode(True, torch.cuda.current_device())
     cfg = {}
     for f in ("config/env_config/dcc.yaml", "config/algo_config/mappo.yaml", "config/expt.yaml"):
         cfg.update(yaml.safe_load(open(os.path.join(PKG, f))))
     cfg.update(num_agents=args.agents, num_pois=args.pois, n_rollout_threads=args.envs * world, n_eval_rollout_threads=0,
                max_ep_len=args.steps_per_launch, ppo_epoch=args.ppo_epoch, save_model=False, n_iters=1,
-               comm_force_scale=args.comm_force_scale, r_comm=args.r_comm, amp_bf16=args.amp_bf16,
-               use_hip_graph=not args.no_graph, compact_obs=args.compact_obs, update_chunk_steps=args.update_chunk_steps,
+               comm_force_scale=args.comm_force_scale, r_comm=args.r_comm,
+               use_hip_graph=not args.no_graph, compact_obs=not args.keep_rows, update_chunk_steps=args.update_chunk_steps,
                structured_input=not args.no_structured_input)
     from learner import Learner
     lr = Learner(Namespace(**cfg))
-    rank = lr.rank
 
     def one_iter():
         t0 = time.perf_counter()
@@ -124,43 +129,98 @@ def bench_mappo(args):
         torch.cuda.synchronize()
         return t1 - t0, time.perf_counter() - t1, info, tinfo
 
-    one_iter()  # warmup (hipBLASLt heuristics, allocator; eager rollout + hipGraph capture)
-    one_iter()  # first graph replay
+    for _ in range(warm_iters):  # hipBLASLt heuristics, allocator, eager rollout + hipGraph capture, first replay
+        one_iter()
+    dist = None
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tr = tu = 0.0
-    for _ in range(args.iters):
+    for _ in range(iters):
         a, b, info, tinfo = one_iter()
         tr += a; tu += b
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt, tr, tu], dtype=torch.float64, device=ptu.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, tr, tu = tt.tolist()
     E, N, T = args.envs, args.agents, args.steps_per_launch
+    rows = T * E * N
+    # algorithmic MLP FLOPs of one iteration: forward = 2 MACs per weight; the update is forward + two
+    # backward GEMMs per layer.  "as_evaluated" = this build's formulation (critic once per env; first layers from the
+    # compact features, 2M/N + 2N + 2 multiply-adds per output instead of D), "reference" = the reference's dense layers
+    # with the critic row duplicated per agent.
+    H, D = 256, 4 + 2 * (N - 1) + 5 * args.pois
+    trunk = 2.0 * (H * H)
+    ref_fwd = 2.0 * (D * H + 2 * H) + trunk + 2.0 * (N * D * H + H) + trunk
+    structured = not args.no_structured_input
+    l1a = 2.0 * ((2 * args.pois / N + 2 * N + 2) * H) if structured else 2.0 * D * H
+    l1c = 2.0 * ((2 * args.pois + (2 * N + 4) * N) * H) if structured else 2.0 * N * D * H
+    ours_fwd = l1a + trunk + 2.0 * 2 * H + (l1c + trunk + 2.0 * H) / N
+    res = {"workload": "c3: %d UAV x %d PoI x %d envs per GPU, full MAPPO iteration = %d policy-driven env steps + HIP GAE "
+                       "+ %d full-batch PPO epochs over %d agent rows; fp32 MLPs (hipBLASLt MFMA GEMMs + fused HIP tails), "
+                       "f64 env state" % (N, args.pois, E, T, args.ppo_epoch, rows),
+           "value": world * E * N * T * iters / dt, "unit": "agent-env-steps/s", "n_gpus": world, "iters_timed": iters,
+           "iters_warmup": warm_iters, "s_per_iter": dt / iters, "rollout_s_per_iter": tr / iters,
+           "update_s_per_iter": tu / iters, "rollout_agent_env_steps_per_sec": world * E * N * T / (tr / iters),
+           "hip_graph_rollout": not args.no_graph, "rows_stored": bool(args.keep_rows), "structured_input": structured,
+           "grad_allreduce": ("%s x%d" % ({"nccl": "rccl"}.get(dist.get_backend(), dist.get_backend()), world)) if world > 1 else "none (1 GPU)",
+           "mlp_tflop_per_iter_reference_formulation": ref_fwd * rows * (1 + 3 * args.ppo_epoch) / 1e12,
+           "mlp_tflop_per_iter_as_evaluated": ours_fwd * rows * (1 + 3 * args.ppo_epoch) / 1e12,
+           "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
+           "train_info": {k: float(v) for k, v in tinfo.items()}, "rollout_info": info}
+    res["update_tflops_as_evaluated"] = ours_fwd * rows * 3 * args.ppo_epoch / 1e12 / (tu / iters)
+    lr.train_envs.close()
+    del lr
+    return res
+
+
+def bench_mappo(args):
+    """--mode mappo: config 3 as the whole line (not the headline)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    m = mappo_iterations(args, args.iters)
+    T = args.steps_per_launch
     steps = args.iters * T
-    res = {"metric": "agent_env_steps_per_sec", "value": world * E * N * steps / dt, "unit": "agent-env-steps/s",
-           "n_gpus": world, "steps": steps, "warmup": T, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+    res = {"metric": "agent_env_steps_per_sec", "value": m["value"], "unit": "agent-env-steps/s",
+           "n_gpus": world, "steps": steps, "warmup": 2 * T, "ms_per_step": m["s_per_iter"] / T * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64 env state / f32 MLPs", "data": "synthetic",
-           "config": {"workload": "c3: %d UAV x %d PoI x %d envs per GPU, full MAPPO iteration = %d policy-driven env "
-                                  "steps + HIP GAE + %d full-batch PPO epochs" % (N, args.pois, E, T, args.ppo_epoch),
-                      "rollout_s_per_iter": tr / args.iters, "update_s_per_iter": tu / args.iters,
-                      "rollout_agent_env_steps_per_sec": world * E * N * T / (tr / args.iters),
-                      "hip_graph_rollout": not args.no_graph, "compact_obs": bool(args.compact_obs), "structured_input": not args.no_structured_input, "update_chunk_steps": args.update_chunk_steps,
-                      "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
-                      "train_info": {k: float(v) for k, v in tinfo.items()}, "rollout_info": info}}
+           "config": m}
     if rank == 0:
         print(json.dumps(res), flush=True)
     return res
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py <same args>`,
+    one rank per GPU (rendezvous on 127.0.0.1)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6000)
-    ap.add_argument("--warmup", type=int, default=600)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; one step = --launches-per-step fused launches")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed warm-up steps")
+    ap.add_argument("--launches-per-step", type=int, default=32,
+                    help="rollouts (fused launches of --steps-per-launch env steps) in one bench step")
     ap.add_argument("--steps-per-launch", type=int, default=150)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=8)
@@ -175,35 +235,36 @@ def main():
     ap.add_argument("--no-assign", action="store_true", help="skip the PoI-assignment output (profiling aid)")
     ap.add_argument("--no-scalars", action="store_true", help="skip reward/done/connect/coverage outputs (profiling aid)")
     ap.add_argument("--mode", choices=["env", "mappo"], default="env",
-                    help="env: BASELINE config 2 (headline); mappo: config 3, full rollout + GAE + PPO update")
+                    help="env: BASELINE config 2 (headline) + a bounded c3 leg; mappo: config 3 only as the whole line")
+    ap.add_argument("--no-c3", action="store_true", help="--mode env: skip the bounded config-3 (MAPPO) leg")
+    ap.add_argument("--c3-iters", type=int, default=2, help="--mode env: timed MAPPO iterations of the c3 leg")
+    ap.add_argument("--c3-timeout", type=float, default=240.0, help="give up on the c3 leg after this many seconds")
     ap.add_argument("--iters", type=int, default=2, help="--mode mappo: timed training iterations")
     ap.add_argument("--ppo-epoch", type=int, default=15)
-    ap.add_argument("--amp-bf16", action="store_true", help="--mode mappo: bf16 autocast in the PPO update")
-    ap.add_argument("--graph", action="store_true", help="--mode mappo: (default) replay the rollout as a hipGraph")
-    ap.add_argument("--no-graph", action="store_true", help="--mode mappo: issue the rollout eagerly from Python")
-    ap.add_argument("--compact-obs", action="store_true",
-                    help="--mode mappo: rollout buffer stores env state, the update regenerates obs per chunk")
-    ap.add_argument("--structured-input", action="store_true", help="--mode mappo: (default) first layers from state features")
+    ap.add_argument("--no-graph", action="store_true", help="mappo: issue the rollout eagerly from Python")
+    ap.add_argument("--keep-rows", action="store_true",
+                    help="mappo: also store the observation rows in the rollout buffer (default: compact env state only)")
     ap.add_argument("--no-structured-input", action="store_true",
-                    help="--mode mappo: dense first layers on the observation rows (reference formulation)")
+                    help="mappo: dense first layers on the observation rows (reference formulation)")
     ap.add_argument("--update-chunk-steps", type=int, default=0,
-                    help="--mode mappo: >0 = chunked full-batch PPO step with gradient accumulation")
+                    help="mappo: >0 = chunked full-batch PPO step with gradient accumulation")
     args = ap.parse_args()
-    if args.mode == "mappo":
-        return bench_mappo(args)
+    if args.no_structured_input:
+        args.keep_rows = True
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the env hot path has no CPU fallback")
     # DCC_BENCH_BACKEND=gloo is a test hook: several ranks may then share one GPU (rendezvous over gloo)
     backend = os.environ.get("DCC_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        os.environ.setdefault("DCC_DIST_BACKEND", "gloo")
     local_dev = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
@@ -215,11 +276,18 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if args.mode == "mappo":
+        import utils.pytorch_utils as ptu
+        ptu.set_gpu_mode(True, local_dev)
+        res = bench_mappo(args)
+        if dist is not None:
+            dist.destroy_process_group()
+        return res
 
     import dcc_hip
     from oracle import oracle  # only for generating the synthetic action stream + cpu_baseline leg
 
-    E, N, M, T = args.envs, args.agents, args.pois, args.steps_per_launch
+    E, N, M, T, L = args.envs, args.agents, args.pois, args.steps_per_launch, args.launches_per_step
     r_cover, crs, cfs, r_comm = 0.2, args.comm_r_scale, args.comm_force_scale, args.r_comm
     poi_all = np.load(os.path.join(PKG, "envs", "mpe", "pos_pois.npy"))
     if M > len(poi_all):
@@ -235,25 +303,18 @@ def main():
         acts = np.stack([oracle.rng_actions(0, k, E, N, rank * E, world * E) for k in range(T)])
         actions = torch.from_numpy(acts).to(dev)
 
-    def launch(k_steps, step0):
-        o = out if k_steps == T else {k: v[:k_steps] for k, v in out.items()}
-        a = actions if (actions is None or k_steps == T) else actions[:k_steps]
-        env.rollout(k_steps, actions=a, seed=0, step0=step0, env0=rank * E, env_total=world * E, out=o)
-
     def run(n_steps, events=None):
-        done, step0 = 0, 0
-        while done < n_steps:
-            k = min(T, n_steps - done)
-            if events is not None and k == T:
+        """n_steps bench steps = n_steps * L fused launches of T env steps, back to back on the current stream."""
+        step0 = 0
+        for _ in range(n_steps * L):
+            if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                launch(k, step0)
+            env.rollout(T, actions=actions, seed=0, step0=step0, env0=rank * E, env_total=world * E, out=out)
+            if events is not None:
                 e1.record()
                 events.append((e0, e1))
-            else:
-                launch(k, step0)
-            done += k
-            step0 += k
+            step0 += T
 
     def barrier():
         if dist is not None:
@@ -275,43 +336,77 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    value = world * E * N * args.steps / dt
+    env_steps = args.steps * L * T          # batched env steps in the timed region
+    value = world * E * N * env_steps / dt
     res = {
         "metric": "agent_env_steps_per_sec", "value": value, "unit": "agent-env-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "c2: %d UAV x %d PoI x %d envs per GPU, random-action env-step HIP kernel only; "
-                               "%d fused env steps per launch, actions %s, obs %s" % (
-                                   N, M, E, T, "read from HBM [T,E,N,2] f32" if actions is not None else "drawn in-kernel",
+        "config": {"workload": "c2 (BASELINE configs[1]): %d UAV x %d PoI x %d envs per GPU, random-action env-step HIP kernel "
+                               "only, weak scaling over GPUs (%d envs job-wide); one bench step = %d rollouts = %d fused launches "
+                               "x %d batched env steps; actions %s, obs %s" % (
+                                   N, M, E, world * E, L, L, T,
+                                   "read from HBM [T,E,N,2] f32" if actions is not None else "drawn in-kernel",
                                    "skipped" if args.no_obs else "written to HBM [T,E,N,D] f32"),
                    "n_agents": N, "n_pois": M, "envs_per_gpu": E, "global_envs": world * E,
-                   "steps_per_launch": T, "comm_force_scale": cfs, "parallelism": "env-shard x%d (no data-path collective)" % world},
+                   "steps_per_launch": T, "launches_per_step": L, "env_steps_per_step": L * T,
+                   "agent_env_steps_per_step": world * E * N * L * T, "timed_region_s": dt,
+                   "comm_force_scale": cfs, "parallelism": "env-shard x%d (no data-path collective)" % world},
     }
-    if events:
-        ms = [a.elapsed_time(b) for a, b in events]
-        avg_ms = sum(ms) / len(ms)
-        bstep = dcc_hip.bytes_per_step(N, M, with_actions=actions is not None, with_obs=not args.no_obs)
-        alg = bstep * E * T
-        ach = alg / (avg_ms * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from the committed PMC passes, when they describe this workload
+    ms = [a.elapsed_time(b) for a, b in events]
+    avg_ms = sum(ms) / len(ms)
+    bstep = dcc_hip.bytes_per_step(N, M, with_actions=actions is not None, with_obs=not args.no_obs)
+    alg = bstep * E * T
+    ach = alg / (avg_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None  # HBM bytes per launch: OFFLINE rocprofv3 PMC passes of this workload, not this run
+    for rnd in ("r02", "r01"):
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic_c2.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic_c2.json")))
             w = tj["workload"]
             if (w["n_agents"], w["n_pois"], w["envs"], w["steps_per_launch"]) == (N, M, E, T) and \
                     (w["actions"] == "hbm") == (actions is not None) and not args.no_obs:
                 traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = "offline rocprofv3 --pmc passes of the same launch (profiles/%s/traffic_c2.json), not measured in this run" % rnd
+                break
         except Exception:
             pass
-        res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
-                           "kernel": "dcc_env_roles_kernel<ACT,FORCE,NC,MC> (c2: <0,false,8,64>); DCC_NO_ROLES=1: dcc_env_kernel<1,0,false,8,64>", "bytes_per_env_step": bstep,
-                           "launch_ms_avg": avg_ms, "launch_ms_min": min(ms), "launches_timed": len(ms),
-                           "frac_of_achievable_6300": ach / 6300.0}
+    sms = sorted(ms)
+    res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                       "algorithmic_bytes_per_launch": alg,
+                       "kernel": "dcc_env_roles_kernel<ACT,FORCE,NC,MC> (c2: <0,false,8,64>); DCC_NO_ROLES=1: dcc_env_kernel<1,0,false,8,64>",
+                       "bytes_per_env_step": bstep, "timing": "HIP events around every timed launch on the launch stream",
+                       "launch_ms_avg": avg_ms, "launch_ms_min": sms[0], "launch_ms_median": sms[len(sms) // 2],
+                       "launch_ms_max": sms[-1], "launches_timed": len(ms), "frac_of_achievable_6300": ach / 6300.0}
+    env.close()
+    del env, out, actions
+    torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs)
-    if rank == 0:
-        print(json.dumps(res), flush=True)
+
+    def emit():
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+
+    if not args.no_c3:
+        # bounded config-3 leg.  It must never cost the headline line: a watchdog prints the line without `c3` and ends
+        # the process if the leg hangs (e.g. a collective that never completes), exceptions are recorded as text.
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(args.c3_timeout):
+                res["c3"] = {"error": "timed out after %.0f s" % args.c3_timeout}
+                emit()
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            res["c3"] = mappo_iterations(args, args.c3_iters)
+        except Exception as e:  # noqa: BLE001
+            res["c3"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        done.set()
+    emit()
     if dist is not None:
         dist.destroy_process_group()
 
