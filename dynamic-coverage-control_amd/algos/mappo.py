@@ -133,8 +133,9 @@ class MAPPOTrainer:
         self._use_policy_active_masks = cfg.use_policy_active_masks
         if cfg.use_popart:
             raise NotImplementedError("PopArt is disabled in the reference config and not built")
-        if cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy:
-            raise NotImplementedError("recurrent generators are disabled in the reference config and not built")
+        self._use_recurrent_policy = bool(cfg.use_recurrent_policy)
+        self._use_naive_recurrent = bool(cfg.use_naive_recurrent_policy)
+        self.data_chunk_length = int(getattr(cfg, "data_chunk_length", 10))
         # reference quirk Q4 (doubled surrogate) on by default; critic de-duplication is exact
         self.double_surrogate = bool(getattr(cfg, "double_surrogate", True))
         self.dedup_critic = bool(getattr(cfg, "dedup_critic", True))
@@ -201,12 +202,12 @@ class MAPPOTrainer:
                       and fused.policy_loss_usable(actions_batch, old_logp))
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp_bf16):
             if fused_loss:      # surrogate, entropy and their gradients in one HIP pass over [B, A] (dcc_ppo_policy_loss)
-                mean = actor._mean(obs_batch, prenormalized)
+                mean = actor._mean(obs_batch, prenormalized, rnn_states_batch, masks_batch)
             else:
                 action_log_probs, dist_entropy = actor.evaluate_actions(
                     obs_batch, rnn_states_batch, actions_batch, masks_batch, available_actions_batch, active_masks_batch,
                     prenormalized=prenormalized)
-            values = self.policy.critic(share_obs_batch, prenormalized=prenormalized)[0]
+            values = self.policy.critic(share_obs_batch, rnn_states_critic_batch, masks_batch, prenormalized=prenormalized)[0]
         values = values.float()
         n_rep = n_rows // values.shape[0]
         fused_vloss = (not self.amp_bf16 and ptu.device.type == "cuda" and fused.value_loss_usable(values)
@@ -389,14 +390,20 @@ class MAPPOTrainer:
                 info[k] = v
             return info
         cached = None
-        if self.cache_normalized_inputs and self.num_mini_batch == 1:
+        recurrent = self._use_recurrent_policy or self._use_naive_recurrent
+        if self.cache_normalized_inputs and self.num_mini_batch == 1 and not recurrent:
             with torch.no_grad():   # parameter-free: (x - mean) / sqrt(var + eps), once for all epochs
                 full = next(buffer.feed_forward_generator(advantages, 1, dedup_critic=self.dedup_critic))
                 cached = (self.policy.critic.base.normalize_input(ptu.to_tensor(full[0])),
                           self.policy.actor.base.normalize_input(ptu.to_tensor(full[1])))
         for _ in range(self.ppo_epoch):
-            for sample in buffer.feed_forward_generator(advantages, self.num_mini_batch,
-                                                        dedup_critic=self.dedup_critic):
+            if self._use_recurrent_policy:        # mappo.py:204-209
+                gen = buffer.recurrent_generator(advantages, self.num_mini_batch, self.data_chunk_length)
+            elif self._use_naive_recurrent:
+                gen = buffer.naive_recurrent_generator(advantages, self.num_mini_batch)
+            else:
+                gen = buffer.feed_forward_generator(advantages, self.num_mini_batch, dedup_critic=self.dedup_critic)
+            for sample in gen:
                 if cached is not None:
                     sample = cached + tuple(sample[2:])
                 vl, cgn, pl, ent, agn, imp = self.ppo_update(sample, update_actor, prenormalized=cached is not None)

@@ -3,15 +3,17 @@
 Both are MLPBase trunks (LayerNorm -> Linear/ReLU/LayerNorm x2) on PyTorch-ROCm: the three GEMMs
 per network are the only dense contractions of the whole hot path and run on MFMA through
 hipBLASLt.  Inputs are expected to live on the device already (the rollout never leaves the GPU);
-numpy inputs are still accepted for drop-in use.  The recurrent / CNN / PopArt variants of the
-reference are disabled by its shipped config (mappo.yaml:21,28-29) and are not built; the cfg keys
-are accepted and must be off.
+numpy inputs are still accepted for drop-in use.  The recurrent variants (`use_recurrent_policy`,
+`use_naive_recurrent_policy`: a GRU + LayerNorm between trunk and head, r_actor_critic.py:36-37,52-53,100-101,117-118)
+are built (algo_utils/rnn.py) although the shipped config keeps them off; the CNN / PopArt variants are not
+(disabled by mappo.yaml, cfg keys accepted and must be off).
 """
 import torch
 import torch.nn as nn
 
 from algos.algo_utils.act import ACTLayer
 from algos.algo_utils.mlp import MLPBase
+from algos.algo_utils.rnn import RNNLayer
 from algos.algo_utils import structured
 from algos.algo_utils.util import init
 from utils.util import check
@@ -21,8 +23,10 @@ from utils.util import get_shape_from_obs_space
 def _require_mlp(cfg, shape):
     if len(shape) != 1:
         raise NotImplementedError("only flat observations are on the coverage hot path")
-    if cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy:
-        raise NotImplementedError("recurrent policies are disabled in the reference config and not built")
+
+
+def _recurrent(cfg):
+    return bool(cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy)
 
 
 class R_Actor(nn.Module):
@@ -34,23 +38,32 @@ class R_Actor(nn.Module):
         obs_shape = get_shape_from_obs_space(obs_space)
         _require_mlp(cfg, obs_shape)
         self.base = MLPBase(cfg, obs_shape)
+        self.rnn = RNNLayer(self.hidden_size, self.hidden_size, cfg.recurrent_N, cfg.use_orthogonal) if _recurrent(cfg) else None
         self.act = ACTLayer(action_space, self.hidden_size, cfg.use_orthogonal, cfg.gain)
         self.obs_layout = None    # set by MAPPOPolicy.enable_structured_input
         self.to(device)
 
-    def _mean(self, obs, prenormalized=False):
+    def _mean(self, obs, prenormalized=False, rnn_states=None, masks=None, want_states=False):
         """Gaussian mean [B, A] = fc_mean(trunk(obs)) (the head is fused with the trunk's last block on the GPU).
-        obs: rows [B, D], or the dict of compact features of B/N env states (algo_utils/structured.py)."""
+        obs: rows [B, D], or the dict of compact features of B/N env states (algo_utils/structured.py).
+        Recurrent variants: fc_mean(rnn(trunk(obs), rnn_states, masks)); want_states also returns the new states."""
         head = self.act.action_out.fc_mean
+        trunk_head = head if self.rnn is None else None
         if isinstance(obs, dict):
             if self.obs_layout is None:
                 raise RuntimeError("compact features passed to an actor without an observation layout")
-            return structured.actor_trunk(self.base, self.obs_layout, obs, head)
-        obs = check(obs).to(**self.tpdv)
-        return self.base.forward_prenormalized(obs, head) if prenormalized else self.base(obs, head)
+            out = structured.actor_trunk(self.base, self.obs_layout, obs, trunk_head)
+        else:
+            obs = check(obs).to(**self.tpdv)
+            out = self.base.forward_prenormalized(obs, trunk_head) if prenormalized else self.base(obs, trunk_head)
+        if self.rnn is not None:
+            feats, rnn_states = self.rnn(out, check(rnn_states).to(**self.tpdv), check(masks).to(**self.tpdv))
+            out = head(feats)
+        return (out, rnn_states) if want_states else out
 
     def forward(self, obs, rnn_states=None, masks=None, available_actions=None, deterministic=False):
-        actions, logp = self.act(None, available_actions, deterministic, mean=self._mean(obs))
+        mean, rnn_states = self._mean(obs, rnn_states=rnn_states, masks=masks, want_states=True)
+        actions, logp = self.act(None, available_actions, deterministic, mean=mean)
         return actions, logp, rnn_states
 
     def evaluate_actions(self, obs, rnn_states, action, masks, available_actions=None, active_masks=None,
@@ -61,7 +74,7 @@ class R_Actor(nn.Module):
             active_masks = check(active_masks).to(**self.tpdv)
         return self.act.evaluate_actions(None, action, available_actions,
                                          active_masks=active_masks if self._use_policy_active_masks else None,
-                                         mean=self._mean(obs, prenormalized))
+                                         mean=self._mean(obs, prenormalized, rnn_states, masks))
 
 
 class R_Critic(nn.Module):
@@ -74,6 +87,7 @@ class R_Critic(nn.Module):
         shape = get_shape_from_obs_space(cent_obs_space)
         _require_mlp(cfg, shape)
         self.base = MLPBase(cfg, shape)
+        self.rnn = RNNLayer(self.hidden_size, self.hidden_size, cfg.recurrent_N, cfg.use_orthogonal) if _recurrent(cfg) else None
         init_method = nn.init.orthogonal_ if cfg.use_orthogonal else nn.init.xavier_uniform_
         self.v_out = init(nn.Linear(self.hidden_size, 1), init_method, lambda b: nn.init.constant_(b, 0))
         self.obs_layout = None
@@ -81,10 +95,15 @@ class R_Critic(nn.Module):
 
     def forward(self, cent_obs, rnn_states=None, masks=None, prenormalized=False):
         """cent_obs: rows [B, N*D], or the dict of compact features of B env states (one value per env)."""
+        head = self.v_out if self.rnn is None else None
         if isinstance(cent_obs, dict):
             if self.obs_layout is None:
                 raise RuntimeError("compact features passed to a critic without an observation layout")
-            return structured.critic_trunk(self.base, self.obs_layout, cent_obs, self.v_out), rnn_states
-        cent_obs = check(cent_obs).to(**self.tpdv)
-        v = self.base.forward_prenormalized(cent_obs, self.v_out) if prenormalized else self.base(cent_obs, self.v_out)
+            v = structured.critic_trunk(self.base, self.obs_layout, cent_obs, head)
+        else:
+            cent_obs = check(cent_obs).to(**self.tpdv)
+            v = self.base.forward_prenormalized(cent_obs, head) if prenormalized else self.base(cent_obs, head)
+        if self.rnn is not None:
+            feats, rnn_states = self.rnn(v, check(rnn_states).to(**self.tpdv), check(masks).to(**self.tpdv))
+            v = self.v_out(feats)
         return v, rnn_states

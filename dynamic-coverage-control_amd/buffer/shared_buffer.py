@@ -78,9 +78,13 @@ class SharedReplayBuffer(object):
         self.masks = torch.ones(T + 1, E, N, 1, dtype=torch.float32, device=self.device)
         self.bad_masks = torch.ones_like(self.masks)
         self.active_masks = torch.ones_like(self.masks)
-        # recurrent policies are not built: zero-width placeholders keep `buffer.rnn_states[t]` indexable
-        self.rnn_states = z(T + 1, E, N, cfg.recurrent_N, 0)
-        self.rnn_states_critic = z(T + 1, E, N, cfg.recurrent_N, 0)
+        # GRU states of the recurrent policy variants (shared_buffer.py:42-45); feed-forward policies (the shipped
+        # setting) get zero-width placeholders that keep `buffer.rnn_states[t]` indexable
+        self.recurrent = bool(cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy)
+        if self.recurrent and self.store_state:
+            raise ValueError("recurrent policies read observation rows: use structured_input: false, compact_obs: false")
+        self.rnn_states = z(T + 1, E, N, cfg.recurrent_N, cfg.algo_hidden_size if self.recurrent else 0)
+        self.rnn_states_critic = torch.zeros_like(self.rnn_states)
         self.available_actions = None
         self.step = 0
 
@@ -206,6 +210,9 @@ class SharedReplayBuffer(object):
         if share_obs is not None and not self._shared_is_view:
             so = self._t(share_obs)
             self._share_obs[s + 1].copy_(so[:, 0] if so.dim() == 3 else so)
+        if self.recurrent and rnn_states_actor is not None:
+            self.rnn_states[s + 1].copy_(self._t(rnn_states_actor).view_as(self.rnn_states[s + 1]))
+            self.rnn_states_critic[s + 1].copy_(self._t(rnn_states_critic).view_as(self.rnn_states_critic[s + 1]))
         self.actions[s].copy_(self._t(actions).view_as(self.actions[s]))
         self.action_log_probs[s].copy_(self._t(action_log_probs).view(self.n_rollout_threads, self.num_agents, -1)
                                        .expand_as(self.action_log_probs[s]))
@@ -229,6 +236,9 @@ class SharedReplayBuffer(object):
             self.obs[0].copy_(self.obs[-1])
         if self._share_obs is not None:
             self._share_obs[0].copy_(self._share_obs[-1])
+        if self.recurrent:
+            self.rnn_states[0].copy_(self.rnn_states[-1])
+            self.rnn_states_critic[0].copy_(self.rnn_states_critic[-1])
         self.masks[0].copy_(self.masks[-1])
         self.bad_masks[0].copy_(self.bad_masks[-1])
         self.active_masks[0].copy_(self.active_masks[-1])
@@ -275,3 +285,59 @@ class SharedReplayBuffer(object):
             so = so_env if dedup_critic else so_env.unsqueeze(1).expand(-1, N, -1).reshape(idx.numel() * N, -1)
             yield (so, g(self.obs[:-1]), None, None, g(self.actions), g(self.value_preds[:-1]), g(self.returns[:-1]),
                    g(self.masks[:-1]), g(self.active_masks[:-1]), g(self.action_log_probs), g(adv), None)
+
+    # ---- recurrent generators (shared_buffer.py:281-487) ----------------------------------------------------------------
+    # The reference builds every mini-batch with Python loops over chunks / env columns and np.stack on host arrays.
+    # Here a mini-batch is ONE advanced-indexing gather per array on the device: the reference's row order is turned
+    # into (t, e, n) index vectors, and the centralised observation is gathered from the per-env view, so only the
+    # mini-batch (never the whole [T,E,N,S] array) is materialised.  The permutation is drawn like the reference draws
+    # it (torch.randperm on the CPU generator), so the same seed selects the same chunks.
+    def _rows(self, t, e, n, advantages):
+        """The 12-tuple of the rows addressed by the index vectors (t, e, n); rnn states are filled in by the callers."""
+        adv = torch.as_tensor(advantages).to(self.device, torch.float32)
+        so = self.share_obs_env[t, e]
+        return [so, self.obs[t, e, n], None, None, self.actions[t, e, n], self.value_preds[t, e, n], self.returns[t, e, n],
+                self.masks[t, e, n], self.active_masks[t, e, n], self.action_log_probs[t, e, n], adv[t, e, n], None]
+
+    def naive_recurrent_generator(self, advantages, num_mini_batch, perm=None):
+        """shared_buffer.py:281-370: whole-episode sequences; a mini-batch is a set of (env, agent) columns.  Rows are
+        time-major [T * cols, .]; rnn states are the columns' states at t = 0."""
+        T, E, N = self.episode_length, self.n_rollout_threads, self.num_agents
+        if not self.recurrent or self.compact:
+            raise RuntimeError("naive_recurrent_generator needs a recurrent, row-storing buffer")
+        batch_size = E * N
+        if batch_size < num_mini_batch:
+            raise ValueError("PPO requires n_rollout_threads (%d) * num_agents (%d) >= num_mini_batch (%d)" % (E, N, num_mini_batch))
+        per = batch_size // num_mini_batch
+        perm = (torch.randperm(batch_size) if perm is None else torch.as_tensor(perm)).to(self.device)
+        tt = torch.arange(T, device=self.device)
+        for start in range(0, batch_size, per):
+            cols = perm[start:start + per]
+            e, n = cols // N, cols % N
+            t_i = tt.view(T, 1).expand(T, cols.numel()).reshape(-1)
+            e_i = e.view(1, -1).expand(T, -1).reshape(-1)
+            n_i = n.view(1, -1).expand(T, -1).reshape(-1)
+            sample = self._rows(t_i, e_i, n_i, advantages)
+            sample[2], sample[3] = self.rnn_states[0, e, n], self.rnn_states_critic[0, e, n]
+            yield tuple(sample)
+
+    def recurrent_generator(self, advantages, num_mini_batch, data_chunk_length, perm=None):
+        """shared_buffer.py:372-487: the (env, agent) sequences are laid end to end (env-major, then agent, then time),
+        cut into chunks of data_chunk_length rows; a mini-batch is a random set of chunks, rows chunk-time-major
+        [L * chunks, .]; rnn states are those stored at each chunk's first row."""
+        T, E, N, L = self.episode_length, self.n_rollout_threads, self.num_agents, int(data_chunk_length)
+        if not self.recurrent or self.compact:
+            raise RuntimeError("recurrent_generator needs a recurrent, row-storing buffer")
+        data_chunks = (E * T * N) // L
+        mb = data_chunks // num_mini_batch
+        perm = (torch.randperm(data_chunks) if perm is None else torch.as_tensor(perm)).to(self.device)
+        off = torch.arange(L, device=self.device)
+        for i in range(num_mini_batch):
+            idx = perm[i * mb:(i + 1) * mb]
+            r = (idx.view(1, -1) * L + off.view(L, 1)).reshape(-1)        # [L * mb] rows in the (e, n, t) flattening
+            e, n, t = r // (N * T), (r // T) % N, r % T
+            sample = self._rows(t, e, n, advantages)
+            r0 = idx * L
+            e0, n0, t0 = r0 // (N * T), (r0 // T) % N, r0 % T
+            sample[2], sample[3] = self.rnn_states[t0, e0, n0], self.rnn_states_critic[t0, e0, n0]
+            yield tuple(sample)

@@ -984,6 +984,15 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
                     write_step_outputs<1>(p, (size_t)k * p.E + env, M, lane, h.rec->R, h.rec->cov, (fl & 1u) != 0u,
                                           (fl & 2u) != 0u, (fl & 4u) != 0u, am, pair);
                 }
+                if (p.st_pos || p.st_vel || p.st_energy || p.st_done) {   // compact post-step (post-reset) state, from the slot
+                    const size_t ko = (size_t)k * p.E + env;
+                    if (p.st_pos && lane < N) p.st_pos[ko * N + lane] = h.apos[lane];
+                    if (p.st_vel && lane < N) p.st_vel[ko * N + lane] = h.avel[lane];
+                    if (lane < M) {
+                        if (p.st_energy) p.st_energy[ko * M + lane] = en[0];
+                        if (p.st_done) p.st_done[ko * M + lane] = (uint8_t)dmask;
+                    }
+                }
                 // both envs of the workgroup: one output stream of 2 L floats
                 if (s == 0) { st.w0 = 0; st.gout = p.obs + ((size_t)k * p.E + env_base) * (size_t)L; }
                 produce_obs<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane,
@@ -1250,8 +1259,7 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
     // (DCC_NO_ROLES=1 forces the fused kernel: tests, A/B)
     // and only for fused multi-step launches: with K = 1 there is nothing to pipeline and the hand-off only adds
     // latency (13.4 vs 14.3 us per single-step launch); DCC_FORCE_ROLES=1 overrides (tests)
-    const bool state_out = p.st_pos || p.st_vel || p.st_energy || p.st_done;
-    if (p.obs != nullptr && env->PPL == 1 && !env->no_roles && !state_out && (p.K >= 2 || env->force_roles)) {
+    if (p.obs != nullptr && env->PPL == 1 && !env->no_roles && (p.K >= 2 || env->force_roles)) {
         kernel_fn fn = pick_roles_kernel(act, p.use_force != 0, p.N, p.M, allow_spec);
         const int grid = (p.E + 1) / 2;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kRolesBlock), env->lds_bytes_roles, s, p);

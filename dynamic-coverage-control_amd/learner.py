@@ -46,6 +46,11 @@ class Learner:
         for k, v in (("double_surrogate", True), ("dedup_critic", True), ("use_hip_graph", False), ("amp_bf16", False)):
             if not hasattr(self.cfg, k):
                 setattr(self.cfg, k, v)
+        self.recurrent = bool(self.cfg.use_recurrent_policy or self.cfg.use_naive_recurrent_policy)
+        if self.recurrent:
+            # the recurrent variants (off in the shipped config) consume observation rows step by step: the rollout buffer
+            # keeps rows and per-(env, agent) GRU states, and the critic runs once per agent row like in the reference
+            self.cfg.structured_input = self.cfg.compact_obs = False
         self.rank, self.world = ptu.init_distributed() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
         utl.seed(self.cfg.seed + self.rank)
 
@@ -160,8 +165,11 @@ class Learner:
         cov_max = torch.zeros(r_envs.n_envs, dtype=torch.float32, device=ptu.device)
         fused_glue = self._fused_glue_ok(r_buffer)
         for cur_step in range(self.max_ep_len):
+            rnn_a = rnn_c = None
             if fused_glue:      # sample + log-prob + buffer insert in one launch (dcc_rollout_sample)
                 actions = self.collect_into(cur_step, r_buffer)
+            elif self.recurrent:
+                values, actions, action_log_probs, rnn_a, rnn_c = self.collect(cur_step, r_buffer)
             else:
                 values, actions, action_log_probs = self.collect(cur_step, r_buffer)
             # rows are written unless the policy reads features AND the buffer does not keep rows
@@ -174,7 +182,7 @@ class Learner:
                                        self.n_agents)
                 r_buffer.step = (cur_step + 1) % r_buffer.episode_length
             else:
-                self.insert((out, values, actions, action_log_probs), r_buffer)
+                self.insert((out, values, actions, action_log_probs, rnn_a, rnn_c), r_buffer)
             rew_sum += out["reward"].double().mean()
             cov_max = torch.maximum(cov_max, out["coverage"])
         self.compute(r_buffer)
@@ -235,6 +243,13 @@ class Learner:
                 values = self.policy.critic(feats)[0].view(E, 1, 1).expand(E, N, 1)
             return values.float(), actions.float().view(E, N, -1).contiguous(), logp.float().view(E, N, 1)
         obs = r_buffer.obs_at(cur_step).view(E * N, -1)
+        if self.recurrent:          # learner.py:231-252 with the GRU states and masks of this step, one critic row per agent
+            masks = r_buffer.masks[cur_step].reshape(E * N, 1)
+            actions, logp, rnn_a = self.policy.actor(obs, r_buffer.rnn_states[cur_step].reshape(E * N, *r_buffer.rnn_states.shape[3:]), masks)
+            values, rnn_c = self.policy.critic(r_buffer.share_obs[cur_step].reshape(E * N, -1),
+                                               r_buffer.rnn_states_critic[cur_step].reshape(E * N, *r_buffer.rnn_states.shape[3:]), masks)
+            return (values.view(E, N, 1), actions.view(E, N, -1).contiguous(), logp.view(E, N, 1),
+                    rnn_a.reshape(E, N, *rnn_a.shape[1:]), rnn_c.reshape(E, N, *rnn_c.shape[1:]))
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.trainer.amp_bf16):
             actions, logp, _ = self.policy.actor(obs)
             if self.trainer.dedup_critic:
@@ -247,7 +262,7 @@ class Learner:
     def _fused_glue_ok(self, r_buffer):
         from algos.algo_utils import fused
         return (ptu.device.type == "cuda" and fused.ENABLED and self.trainer.dedup_critic and not self.trainer.amp_bf16
-                and r_buffer.act_dim <= fused.HEAD_MAX_OUT)
+                and r_buffer.act_dim <= fused.HEAD_MAX_OUT and not self.recurrent)
 
     @torch.no_grad()
     def collect_into(self, cur_step, r_buffer):
@@ -272,11 +287,14 @@ class Learner:
 
     def insert(self, data, r_buffer):
         """masks = 0 where the env finished (learner.py:254-276); obs[t+1] is already in place."""
-        out, values, actions, action_log_probs = data
+        out, values, actions, action_log_probs, rnn_a, rnn_c = data
         E, N = r_buffer.n_rollout_threads, self.n_agents
         masks = (1.0 - out["done"].to(torch.float32)).view(E, 1, 1).expand(E, N, 1)
         rewards = out["reward"].view(E, 1, 1).expand(E, N, 1)
-        r_buffer.insert(None, None, None, None, actions, action_log_probs, values, rewards, masks)
+        if rnn_a is not None:      # GRU states of finished envs restart from zero (learner.py:258-265)
+            keep = masks.reshape(E, N, 1, 1)
+            rnn_a, rnn_c = rnn_a * keep, rnn_c * keep
+        r_buffer.insert(None, None, rnn_a, rnn_c, actions, action_log_probs, values, rewards, masks)
 
     @torch.no_grad()
     def compute(self, r_buffer):
@@ -284,6 +302,12 @@ class Learner:
         self.trainer.prep_rollout()
         E, N = r_buffer.n_rollout_threads, self.n_agents
         last = r_buffer.episode_length
+        if self.recurrent:          # learner.py:278-287
+            next_values = self.policy.critic(r_buffer.share_obs[last].reshape(E * N, -1),
+                                             r_buffer.rnn_states_critic[last].reshape(E * N, *r_buffer.rnn_states.shape[3:]),
+                                             r_buffer.masks[last].reshape(E * N, 1))[0].view(E, N, 1)
+            r_buffer.compute_returns(next_values, self.trainer.value_normalizer)
+            return
         cent = r_buffer.features_at(last) if r_buffer.structured else r_buffer.share_obs_env_at(last)
         next_values = self.policy.critic(cent)[0].view(E, 1, 1).expand(E, N, 1)
         r_buffer.compute_returns(next_values, self.trainer.value_normalizer)
@@ -359,10 +383,16 @@ class Learner:
         rec = {k: [] for k in ("pos", "energy", "reward", "done", "coverage", "connect")}
         first_done = torch.full((E,), -1, dtype=torch.int32, device=ptu.device)
         cov_max = torch.zeros(E, device=ptu.device)
+        rnn = masks = None
+        if self.recurrent:
+            rnn = torch.zeros(E * N, self.cfg.recurrent_N, self.cfg.algo_hidden_size, device=ptu.device)
+            masks = torch.ones(E * N, 1, device=ptu.device)
         for t in range(T):
-            actions, _, _ = self.policy.actor(obs.view(E * N, -1), deterministic=deterministic)
+            actions, _, rnn = self.policy.actor(obs.view(E * N, -1), rnn, masks, deterministic=deterministic)
             out = envs.step_device(actions.view(E, N, -1).contiguous())
             obs = out["obs"]
+            if self.recurrent:
+                masks = (1.0 - out["done"].float()).view(E, 1).expand(E, N).reshape(E * N, 1)
             cov_max = torch.maximum(cov_max, out["coverage"])
             full = (out["coverage"] >= 1.0) & (first_done < 0)
             first_done = torch.where(full, torch.full_like(first_done, t + 1), first_done)

@@ -73,7 +73,8 @@ def test_learner_runs_and_improves_nothing_breaks(tmp_path):
     assert os.path.exists(os.path.join(lr.output_path, "models_2.pt", "agent.pkl"))
     # rollout invariants on the device buffer
     b = lr.rl_buffer
-    assert torch.isfinite(b.returns).all() and torch.isfinite(b.obs).all()
+    assert b.compact and b.structured and b.obs is None       # shipped default: compact env state, no observation rows
+    assert torch.isfinite(b.returns).all() and torch.isfinite(b.state_pos).all() and torch.isfinite(b.obs_rows(0, 21)).all()
     assert bool(((b.masks == 0) | (b.masks == 1)).all())
     # values identical across the agents of an env (centralised critic evaluated once per env)
     assert float((b.value_preds - b.value_preds[:, :, :1]).abs().max()) == 0.0
@@ -94,7 +95,7 @@ def test_rollout_obs_in_buffer_equal_oracle_replay(oracle_mod):
     from learner import Learner
     from envs.hip_vec_env import load_pois
     cfg = _cfg(n_rollout_threads=16, n_eval_rollout_threads=0, num_agents=4, num_pois=16, max_ep_len=30, n_iters=1,
-               ppo_epoch=1, algo_hidden_size=32, save_model=False)
+               ppo_epoch=1, algo_hidden_size=32, save_model=False, compact_obs=False)
     lr = Learner(cfg)
     torch.manual_seed(0)
     lr.rollout(lr.rl_buffer, lr.train_envs)
@@ -220,7 +221,7 @@ def test_compact_state_buffer_trains_like_the_full_buffer():
     kw = dict(n_rollout_threads=48, n_eval_rollout_threads=0, num_agents=8, num_pois=64, max_ep_len=25, n_iters=1,
               ppo_epoch=3, algo_hidden_size=64, save_model=False, seed=5, cache_normalized_inputs=False)
     kw["structured_input"] = False          # dense first layers on rows: stored (full) vs regenerated per chunk (comp)
-    full = Learner(_cfg(**kw))
+    full = Learner(_cfg(**dict(kw, compact_obs=False)))
     comp = Learner(_cfg(**dict(kw, compact_obs=True, update_chunk_steps=7)))
     for (k, a), (_, b) in zip(full.policy.actor.state_dict().items(), comp.policy.actor.state_dict().items()):
         assert torch.equal(a, b), k
@@ -255,7 +256,7 @@ def test_structured_input_trains_like_the_full_buffer():
     kw = dict(n_rollout_threads=40, n_eval_rollout_threads=0, num_agents=8, num_pois=64, max_ep_len=20, n_iters=1,
               ppo_epoch=3, algo_hidden_size=64, save_model=False, seed=9, cache_normalized_inputs=False)
     st = Learner(_cfg(**dict(kw, structured_input=True, compact_obs=True, update_chunk_steps=8)))
-    full = Learner(_cfg(**dict(kw, structured_input=False)))
+    full = Learner(_cfg(**dict(kw, structured_input=False, compact_obs=False)))
     torch.manual_seed(4)
     r = st.rollout(st.rl_buffer, st.train_envs)
     sb, fb = st.rl_buffer, full.rl_buffer
@@ -320,11 +321,11 @@ def test_structured_learner_full_train_loop_with_eval_envs(tmp_path):
     from learner import Learner
     cfg = _cfg(n_rollout_threads=64, n_eval_rollout_threads=16, num_agents=4, num_pois=20, max_ep_len=15, n_iters=3,
                ppo_epoch=2, algo_hidden_size=64, save_model=True, save_interval=3, eval_interval=1, log_interval=1,
-               main_save_path=str(tmp_path), structured_input=True)
+               main_save_path=str(tmp_path), structured_input=True, compact_obs=False)
     lr = Learner(cfg)
     lr.train()
     assert lr.rl_buffer.structured and lr.test_buffer.structured and len(lr._graphs) == 2
-    assert lr.rl_buffer.obs is not None and not lr.rl_buffer.compact       # shipped default: features AND rows
+    assert lr.rl_buffer.obs is not None and not lr.rl_buffer.compact       # compact_obs: false -> features AND rows
     assert os.path.exists(os.path.join(lr.output_path, "models_3.pt", "agent.pkl"))
     lr2 = Learner(_cfg(**dict(vars(cfg), save_model=False, seed=7)))
     lr2.load_checkpoint(os.path.join(lr.output_path, "models_3.pt", "resume.pt"))
@@ -387,4 +388,28 @@ def test_fused_rollout_glue_fills_the_buffer_like_collect_and_insert():
     np.testing.assert_allclose(A.action_log_probs.cpu().numpy(), B.action_log_probs.cpu().numpy(), rtol=0, atol=2e-6)
     assert int((A.masks == 0).sum()) == int((B.masks == 0).sum()) and A.step == B.step
     assert ra == rb
+    ptu.set_gpu_mode(False)
+
+
+@pytest.mark.parametrize("mode", ["use_recurrent_policy", "use_naive_recurrent_policy"])
+def test_recurrent_policy_variants_train_on_the_device(mode):
+    """GRU policies (off in the shipped config) through the whole loop on the GPU -- per-(env, agent)
+    GRU states in the rollout buffer, zeroed when an env finishes, chunked / whole-episode generators, eval rollout."""
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    lr = Learner(_cfg(n_rollout_threads=12, n_eval_rollout_threads=0, num_agents=4, num_pois=16, max_ep_len=40, n_iters=1,
+                      ppo_epoch=2, algo_hidden_size=32, save_model=False, num_mini_batch=2, data_chunk_length=5,
+                      use_hip_graph=False, **{mode: True}))
+    b = lr.rl_buffer
+    assert lr.recurrent and b.recurrent and not b.structured and not b.compact and b.rnn_states.shape == (41, 12, 4, 1, 32)
+    for _ in range(2):
+        r = lr.rollout(b, lr.train_envs)
+        info = lr.rl_update()
+        assert np.isfinite(r["reward"]) and all(np.isfinite(v) for v in info.values())
+    assert float(b.rnn_states[1:].abs().sum()) > 0
+    done_next = b.masks[1:, :, :, 0] == 0                      # state stored after a finishing step restarts from zero
+    assert float(b.rnn_states[1:][done_next].abs().sum()) == 0.0
+    res = lr.evaluate(steps=10)
+    assert 0.0 <= res["coverage_rate"] <= 1.0
     ptu.set_gpu_mode(False)
