@@ -11,9 +11,12 @@ What is MI355X-first:
   * every tensor of the update already lives on the GPU (no per-epoch host gather of B x (D+S));
   * the centralised critic input is identical for the N agents of an env (learner.py:269-271), so
     with `dedup_critic` it is evaluated once per env and broadcast (N x fewer critic FLOPs);
-  * one process per GPU: gradients are summed over ranks with one flat RCCL all-reduce per network
-    BEFORE clipping (so the clip sees the global gradient); advantage statistics and ValueNorm
-    moments are all-reduced too, which makes G ranks on E/G envs each equivalent to one rank on E.
+  * parameters, gradients and Adam moments of each network are flat arrays (algo_utils/optim.py): clipping + Adam is
+    three HIP launches per network (include/dcc_optim.h), zero_grad one memset;
+  * one process per GPU: the flat gradient arrays are all-reduced over RCCL in place, BEFORE clipping (so the clip
+    sees the global gradient); the critic's all-reduce is in flight while the actor's backward runs; advantage
+    statistics and ValueNorm moments are all-reduced too, which makes G ranks on E/G envs each equivalent to one
+    rank on E.
 """
 import os
 import pickle
@@ -23,9 +26,10 @@ import torch.nn as nn
 
 import utils.pytorch_utils as ptu
 from algos.algo_utils import fused
+from algos.algo_utils.optim import FlatAdam
 from algos.algo_utils.structured import invalidate_folded_weights
 from algos.r_actor_critic import R_Actor, R_Critic
-from utils.util import get_gard_norm, huber_loss, mse_loss, update_linear_schedule
+from utils.util import huber_loss, mse_loss, update_linear_schedule
 from utils.valuenorm import ValueNorm
 
 
@@ -42,16 +46,10 @@ class MAPPOPolicy:
         self.obs_space, self.share_obs_space, self.act_space = obs_space, cent_obs_space, act_space
         self.actor = R_Actor(cfg, obs_space, act_space, ptu.device)
         self.critic = R_Critic(cfg, cent_obs_space, ptu.device)
-        # cfg.use_hip_graph_update: each PPO epoch (forward, backward, clipping, Adam) is replayed as one hipGraph.  That
-        # needs Adam's step counter and learning rate on the device (capturable=True, tensor lr): same update rule,
-        # bias corrections evaluated in float32 on the GPU instead of Python floats.
-        self.capturable = bool(getattr(cfg, "use_hip_graph_update", False)) and ptu.device.type == "cuda"
-        mk_lr = (lambda v: torch.tensor(float(v), device=ptu.device)) if self.capturable else (lambda v: v)
-        extra = dict(capturable=True) if self.capturable else {}
-        self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=mk_lr(self.actor_lr), eps=self.opti_eps,
-                                                weight_decay=self.weight_decay, **extra)
-        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=mk_lr(self.critic_lr), eps=self.opti_eps,
-                                                 weight_decay=self.weight_decay, **extra)
+        self.actor_optimizer = FlatAdam(self.actor.parameters(), lr=self.actor_lr, eps=self.opti_eps,
+                                        weight_decay=self.weight_decay)
+        self.critic_optimizer = FlatAdam(self.critic.parameters(), lr=self.critic_lr, eps=self.opti_eps,
+                                         weight_decay=self.weight_decay)
 
     def enable_structured_input(self, layout):
         """Let actor and critic accept compact features (algo_utils/structured.py) in place of observation rows."""
@@ -100,21 +98,21 @@ class MAPPOPolicy:
             self.critic_optimizer.load_state_dict(sd["critic_optimizer"])
 
 
-def _allreduce_grads(params):
-    """Sum gradients over ranks with ONE flat all-reduce, then divide by the world size (each rank's
-    loss is a mean over its own equally sized batch shard, so the mean of means is the global mean)."""
+def _allreduce_start(opt):
+    """Start the sum of `opt`'s flat gradient array over the ranks (asynchronous; None on a single process)."""
     dist = _dist()
     if dist is None:
+        return None
+    return dist.all_reduce(opt.flat_grad, async_op=True)
+
+
+def _allreduce_finish(opt, work):
+    """Wait for the all-reduce and turn the sum into the mean (each rank's loss is a mean over its own equally sized
+    batch shard, so the mean of the per-rank gradients is the gradient of the global mean)."""
+    if work is None:
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat)
-    flat /= dist.get_world_size()
-    off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
-        off += n
+    work.wait()
+    opt.flat_grad.div_(_dist().get_world_size())
 
 
 class MAPPOTrainer:
@@ -139,25 +137,11 @@ class MAPPOTrainer:
         # reference quirk Q4 (doubled surrogate) on by default; critic de-duplication is exact
         self.double_surrogate = bool(getattr(cfg, "double_surrogate", True))
         self.dedup_critic = bool(getattr(cfg, "dedup_critic", True))
-        # optional bf16 autocast of the update's GEMMs (MFMA bf16 = 16x the f32-MFMA rate); off by default
-        # because the reference trains in fp32
-        self.amp_bf16 = bool(getattr(cfg, "amp_bf16", False)) and ptu.device.type == "cuda"
         # compute the parameter-free part of the input LayerNorm once per train() instead of once per epoch
         self.cache_normalized_inputs = bool(getattr(cfg, "cache_normalized_inputs", True))
         # > 0: visit the batch in chunks of this many rollout steps with gradient accumulation (exact);
         # required by (and defaulted for) the compact-state rollout buffer
         self.update_chunk_steps = int(getattr(cfg, "update_chunk_steps", 0))
-        # EXPERIMENTAL, off by default: replay each chunked PPO epoch as one hipGraph (single GPU, fp32; needs the policy's
-        # capturable optimizers).  NOT RELIABLE on this stack (ROCm 7.2, PyTorch 2.10+rocm7.0): multi-block torch reductions inside a replayed graph start returning wrong values after
-        # some hundreds of replays (stand-alone reproduction: tools/graph_reduce_probe.py), and an epoch is full of them
-        # (loss means, ValueNorm moments, gradient norms): observed as corrupted ValueNorm statistics after 3-26
-        # iterations at 614 k rows.  The rollout graph (use_hip_graph) has no such reduction.
-        self.graph_update = (bool(getattr(cfg, "use_hip_graph_update", False)) and getattr(policy, "capturable", False)
-                             and _dist() is None and not bool(getattr(cfg, "amp_bf16", False)))
-        # large batches are GPU-bound (c3: 37 ms of kernels per epoch) and would only pay the graph's private memory pool;
-        # the replay is for launch-bound batches (shipped task, 16 envs: ~350 launches of a few us per epoch)
-        self.graph_update_max_rows = int(getattr(cfg, "graph_update_max_rows", 1000000))
-        self._epoch_graphs, self._adv_static = {}, {}
         self.value_normalizer = ValueNorm(1, device=ptu.device) if self._use_valuenorm else None
 
     # ---- losses ---------------------------------------------------------------------------------
@@ -197,21 +181,20 @@ class MAPPOTrainer:
             obs_batch, share_obs_batch = t(obs_batch), t(share_obs_batch)
         n_rows = actions_batch.shape[0]
 
+        if not self.double_surrogate:      # single log-prob column: the PPO surrogate without the reference's doubling (Q4)
+            old_logp = old_logp[:, :1]
         actor = self.policy.actor
-        fused_loss = (not self.amp_bf16 and ptu.device.type == "cuda" and available_actions_batch is None
-                      and fused.policy_loss_usable(actions_batch, old_logp))
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp_bf16):
-            if fused_loss:      # surrogate, entropy and their gradients in one HIP pass over [B, A] (dcc_ppo_policy_loss)
-                mean = actor._mean(obs_batch, prenormalized, rnn_states_batch, masks_batch)
-            else:
-                action_log_probs, dist_entropy = actor.evaluate_actions(
-                    obs_batch, rnn_states_batch, actions_batch, masks_batch, available_actions_batch, active_masks_batch,
-                    prenormalized=prenormalized)
-            values = self.policy.critic(share_obs_batch, rnn_states_critic_batch, masks_batch, prenormalized=prenormalized)[0]
-        values = values.float()
+        on_gpu = ptu.device.type == "cuda"
+        fused_loss = on_gpu and available_actions_batch is None and fused.policy_loss_usable(actions_batch, old_logp)
+        if fused_loss:      # surrogate, entropy and their gradients in one HIP pass over [B, A] (dcc_ppo_policy_loss)
+            mean = actor._mean(obs_batch, prenormalized, rnn_states_batch, masks_batch)
+        else:
+            action_log_probs, dist_entropy = actor.evaluate_actions(
+                obs_batch, rnn_states_batch, actions_batch, masks_batch, available_actions_batch, active_masks_batch,
+                prenormalized=prenormalized)
+        values = self.policy.critic(share_obs_batch, rnn_states_critic_batch, masks_batch, prenormalized=prenormalized)[0]
         n_rep = n_rows // values.shape[0]
-        fused_vloss = (not self.amp_bf16 and ptu.device.type == "cuda" and fused.value_loss_usable(values)
-                       and values.shape[0] * n_rep == n_rows)
+        fused_vloss = on_gpu and fused.value_loss_usable(values) and values.shape[0] * n_rep == n_rows
         if values.shape[0] != n_rows and not fused_vloss:
             values = values.unsqueeze(1).expand(-1, n_rep, -1).reshape(-1, 1)
 
@@ -220,7 +203,6 @@ class MAPPOTrainer:
                 mean, actor.act.action_out.logstd._bias.view(-1), actions_batch, old_logp, adv_targ, active_masks_batch,
                 self.clip_param, self._use_policy_active_masks)
         else:
-            action_log_probs, dist_entropy = action_log_probs.float(), dist_entropy.float()
             imp_weights = torch.exp(action_log_probs - old_logp)   # [B, A] when old_logp keeps the reference's [.,2] layout
             surr1 = imp_weights * adv_targ
             surr2 = torch.clamp(imp_weights, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_targ
@@ -242,19 +224,37 @@ class MAPPOTrainer:
             value_loss = self.cal_value_loss(values, value_preds_batch, return_batch, active_masks_batch, update_norm)
         return policy_loss, dist_entropy, value_loss, imp_weights
 
-    def _optimizer_step(self):
-        """all-reduce (multi-GPU) -> clip -> Adam, for both networks (mappo.py:176-185)."""
-        actor_params = list(self.policy.actor.parameters())
-        critic_params = list(self.policy.critic.parameters())
-        _allreduce_grads(actor_params)
-        _allreduce_grads(critic_params)
-        if self._use_max_grad_norm:
-            actor_grad_norm = nn.utils.clip_grad_norm_(actor_params, self.max_grad_norm)
-            critic_grad_norm = nn.utils.clip_grad_norm_(critic_params, self.max_grad_norm)
-        else:
-            actor_grad_norm, critic_grad_norm = get_gard_norm(actor_params), get_gard_norm(critic_params)
-        self.policy.actor_optimizer.step()
-        self.policy.critic_optimizer.step()
+    def _backward(self, policy_loss, dist_entropy, value_loss, update_actor, weight=1.0, last=True):
+        """total_loss.backward() of mappo.py:166-174.  Actor and critic share no parameter, so the total is the sum of two
+        independent graphs; in a multi-GPU job the critic's is run first and -- on the last (or only) chunk of the batch --
+        its flat gradient starts its RCCL all-reduce while the actor's backward is still running.  Returns the pending
+        all-reduces [(optimizer, work)]."""
+        critic_loss = value_loss * self.value_loss_coef
+        actor_loss = (policy_loss - dist_entropy * self.entropy_coef) if update_actor else None
+        if weight != 1.0:
+            critic_loss = critic_loss * weight
+            actor_loss = actor_loss * weight if actor_loss is not None else None
+        if _dist() is None:
+            (critic_loss if actor_loss is None else actor_loss + critic_loss).backward()
+            return []
+        pending = []
+        critic_loss.backward()
+        if last:
+            pending.append((self.policy.critic_optimizer, _allreduce_start(self.policy.critic_optimizer)))
+        if actor_loss is not None:
+            actor_loss.backward()
+        if last:
+            pending.append((self.policy.actor_optimizer, _allreduce_start(self.policy.actor_optimizer)))
+        return pending
+
+    def _optimizer_step(self, pending=()):
+        """finish the all-reduces (multi-GPU) -> clip -> Adam, for both networks (mappo.py:176-185): three launches per
+        network on the flat arrays (include/dcc_optim.h).  Returns the two pre-clip gradient norms as 0-d tensors."""
+        for opt, work in pending:
+            _allreduce_finish(opt, work)
+        max_norm = self.max_grad_norm if self._use_max_grad_norm else None     # None: norm only (get_gard_norm)
+        actor_grad_norm = self.policy.actor_optimizer.clip_and_step(max_norm)
+        critic_grad_norm = self.policy.critic_optimizer.clip_and_step(max_norm)
         invalidate_folded_weights(self.policy.actor, self.policy.critic)
         return actor_grad_norm, critic_grad_norm
 
@@ -264,14 +264,10 @@ class MAPPOTrainer:
         If `share_obs_batch` has fewer rows than `obs_batch` it holds ONE row per (step, env) and the
         values are broadcast over the agents (dedup_critic)."""
         policy_loss, dist_entropy, value_loss, imp_weights = self._forward_losses(sample, prenormalized)
-        if update_actor:
-            total_loss = (policy_loss - dist_entropy * self.entropy_coef) + value_loss * self.value_loss_coef
-        else:
-            total_loss = value_loss * self.value_loss_coef
-        self.policy.actor_optimizer.zero_grad(set_to_none=False)
-        self.policy.critic_optimizer.zero_grad(set_to_none=False)
-        total_loss.backward()
-        actor_grad_norm, critic_grad_norm = self._optimizer_step()
+        self.policy.actor_optimizer.zero_grad()
+        self.policy.critic_optimizer.zero_grad()
+        pending = self._backward(policy_loss, dist_entropy, value_loss, update_actor)
+        actor_grad_norm, critic_grad_norm = self._optimizer_step(pending)
         return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights
 
     def ppo_update_chunked(self, buffer, advantages, update_actor=True):
@@ -286,63 +282,25 @@ class MAPPOTrainer:
             self.value_normalizer.update(buffer.returns[:-1].reshape(-1, 1))
         # every row is active on this path (the env never deactivates an agent), so a chunk's weight is its row share
         total_rows = float(T * buffer.n_rollout_threads * buffer.num_agents)
-        self.policy.actor_optimizer.zero_grad(set_to_none=False)
-        self.policy.critic_optimizer.zero_grad(set_to_none=False)
-        acc = None
+        self.policy.actor_optimizer.zero_grad()
+        self.policy.critic_optimizer.zero_grad()
+        acc, pending = None, []
         for t0 in range(0, T, step):
             t1 = min(T, t0 + step)
             sample = buffer.chunk_sample(advantages, t0, t1, dedup_critic=self.dedup_critic)
             w = sample[4].shape[0] / total_rows
             policy_loss, dist_entropy, value_loss, imp_weights = self._forward_losses(sample, False, update_norm=False)
-            if update_actor:
-                loss = (policy_loss - dist_entropy * self.entropy_coef) + value_loss * self.value_loss_coef
-            else:
-                loss = value_loss * self.value_loss_coef
-            (loss * w).backward()
+            pending = self._backward(policy_loss, dist_entropy, value_loss, update_actor, weight=w, last=t1 == T)
             part = torch.stack([value_loss.detach(), policy_loss.detach(), dist_entropy.detach(),
                                 imp_weights.detach().mean()]).double() * w
             acc = part if acc is None else acc + part
-        actor_grad_norm, critic_grad_norm = self._optimizer_step()
+        actor_grad_norm, critic_grad_norm = self._optimizer_step(pending)
         return acc[0], critic_grad_norm, acc[1], acc[2], actor_grad_norm, acc[3]
 
-    def _epoch_metrics(self, buffer, advantages, update_actor):
-        vl, cgn, pl, ent, agn, ratio = self.ppo_update_chunked(buffer, advantages, update_actor)
-        dev = vl.device
-        return torch.stack([vl.double(), pl.double(), ent.double(), torch.as_tensor(agn, device=dev).double(),
-                            torch.as_tensor(cgn, device=dev).double(), ratio.double()])
-
     def _epoch(self, buffer, advantages, update_actor):
-        """One chunked full-batch PPO epoch -> metrics [6] (float64).  With use_hip_graph_update the epoch is captured
-        after its first eager execution and replayed from then on (its inputs are static: buffer arrays, the persistent
-        per-chunk feature buffers, the static advantage buffer, parameters / optimizer state updated in place)."""
-        rows = buffer.episode_length * buffer.n_rollout_threads * buffer.num_agents
-        if not self.graph_update or rows > self.graph_update_max_rows:
-            return self._epoch_metrics(buffer, advantages, update_actor)
-        key = (id(buffer), bool(update_actor), advantages.data_ptr())
-        hit = self._epoch_graphs.get(key)
-        if hit is not None:
-            hit[0].replay()
-            invalidate_folded_weights(self.policy.actor, self.policy.critic)   # the replay stepped the parameters
-            return hit[1]
-        m = self._epoch_metrics(buffer, advantages, update_actor)       # really executes (and warms allocator / hipBLASLt)
-        try:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                ms = self._epoch_metrics(buffer, advantages, update_actor)
-            self._epoch_graphs[key] = (g, ms)
-        except Exception as e:      # an optimisation only: keep training eagerly
-            print("hipGraph capture of the PPO epoch failed (%s); continuing eagerly" % e)
-            self.graph_update = False
-            torch.cuda.synchronize()
-        return m
-
-    def _static_advantages(self, buffer, advantages):
-        buf = self._adv_static.get(id(buffer))
-        if buf is None or buf.shape != advantages.shape:
-            buf = self._adv_static[id(buffer)] = torch.empty_like(advantages)
-        buf.copy_(advantages)
-        return buf
+        """One chunked full-batch PPO epoch -> metrics [6] (float64, on the device)."""
+        vl, cgn, pl, ent, agn, ratio = self.ppo_update_chunked(buffer, advantages, update_actor)
+        return torch.stack([vl.double(), pl.double(), ent.double(), agn.double(), cgn.double(), ratio.double()])
 
     # ---- one training phase -------------------------------------------------------------------------
     def normalized_advantages(self, buffer):
@@ -380,8 +338,6 @@ class MAPPOTrainer:
                 T, step = buffer.episode_length, max(1, int(self.update_chunk_steps))
                 for t0 in range(0, T, step):
                     buffer.features_rows(t0, min(T, t0 + step))
-            if self.graph_update:
-                advantages = self._static_advantages(buffer, advantages)
             for _ in range(self.ppo_epoch):
                 acc += self._epoch(buffer, advantages, update_actor)
             acc /= self.ppo_epoch
@@ -407,9 +363,8 @@ class MAPPOTrainer:
                 if cached is not None:
                     sample = cached + tuple(sample[2:])
                 vl, cgn, pl, ent, agn, imp = self.ppo_update(sample, update_actor, prenormalized=cached is not None)
-                acc += torch.stack([vl.detach().double(), pl.detach().double(), ent.detach().double(),
-                                    torch.as_tensor(agn, device=acc.device).double(),
-                                    torch.as_tensor(cgn, device=acc.device).double(), imp.detach().mean().double()])
+                acc += torch.stack([vl.detach().double(), pl.detach().double(), ent.detach().double(), agn.double(), cgn.double(),
+                                    imp.detach().mean().double()])
         acc /= (self.ppo_epoch * self.num_mini_batch)
         vals = acc.tolist()   # the only host sync of the update
         for k, v in zip(("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"), vals):
@@ -436,9 +391,35 @@ class MAPPOTrainer:
             pickle.dump(sd, f)
 
     def load_model(self, load_path):
+        """Reads this package's agent.pkl (a dict of state_dicts) and also a checkpoint written by the REFERENCE
+        (mappo.py:236-247 pickles the whole MAPPOPolicy object): its parameters are taken over, the never-trained
+        `mlp.fc_h` template is dropped, optimizer moments and ValueNorm -- which the reference's pickle does
+        not carry in a usable form / at all -- start fresh."""
         with open(os.path.join(load_path, "agent.pkl"), "rb") as f:
-            sd = pickle.load(f)
+            sd = _CheckpointUnpickler(f).load()
+        if not isinstance(sd, dict):
+            live = lambda m: {k: v for k, v in m.state_dict().items() if ".fc_h." not in k}
+            sd = {"actor": live(sd.actor), "critic": live(sd.critic)}
         self.policy.load_state_dict(sd)
         if self.value_normalizer is not None and "value_normalizer" in sd:
             self.value_normalizer.load_state_dict(sd["value_normalizer"])
-        self.policy.actor.to(ptu.device); self.policy.critic.to(ptu.device)
+        invalidate_folded_weights(self.policy.actor, self.policy.critic)
+
+
+class _Opaque(object):
+    """Stand-in for classes a pickled reference policy mentions that do not exist here (gym spaces, ...): holds state,
+    does nothing."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        self.__dict__["_state"] = state
+
+
+class _CheckpointUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except (ImportError, AttributeError):
+            return _Opaque

@@ -29,6 +29,7 @@
 #include <string>
 
 #include "dcc_env.h"
+#include "dcc_internal.h"
 
 namespace {
 
@@ -1148,10 +1149,7 @@ __global__ __launch_bounds__(kSplitBlock, (PPL >= 8 || FORCE ? 1 : 2)) void dcc_
 
 thread_local std::string g_err;
 
-int fail(int code, const std::string& msg) {
-    g_err = msg;
-    return code;
-}
+int fail(int code, const std::string& msg) { return dcc_fail(code, msg); }
 
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
@@ -1161,6 +1159,12 @@ int fail(int code, const std::string& msg) {
     } while (0)
 
 }  // namespace
+
+// the one error slot of the library: dcc_env_*, dcc_obs_*, dcc_gae_*, the dcc_mlp.h and dcc_optim.h entry points all report here
+int dcc_fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
 
 struct dcc_env {
     dcc_env_cfg cfg;

@@ -12,6 +12,7 @@
 #include <string>
 
 #include "dcc_gae.h"
+#include "dcc_internal.h"
 
 namespace {
 
@@ -54,8 +55,6 @@ __global__ __launch_bounds__(256) void dcc_gae_kernel(const float* __restrict__ 
     }
 }
 
-thread_local std::string g_gae_err;
-
 }  // namespace
 
 extern "C" {
@@ -63,16 +62,18 @@ extern "C" {
 DCC_API int dcc_gae_compute(const float* rewards, const float* value_preds, const float* masks, const float* denorm,
                             double gamma, double gae_lambda, float* returns, float* advantages, int32_t T, int64_t C,
                             void* stream) {
-    if (!rewards || !value_preds || !masks || !returns || T < 1 || C < 1) return -1;
+    if (!rewards || !value_preds || !masks || !returns) return dcc_fail(-1, "dcc_gae_compute: rewards / value_preds / masks / returns must not be NULL");
+    if (T < 1 || C < 1) return dcc_fail(-1, "dcc_gae_compute: T and C must be >= 1");
     const int block = 256;
     const long long grid = (C + block - 1) / block;
-    if (grid > 0x7fffffffLL) return -1;
+    if (grid > 0x7fffffffLL) return dcc_fail(-1, "dcc_gae_compute: too many columns for one launch");
     // numpy turns the Python floats into float32 scalars: gamma -> f32(gamma), gamma*lambda (computed
     // in float64 first, shared_buffer.py:206 evaluates left to right) -> f32
     const float g = (float)gamma, gl = (float)(gamma * gae_lambda);
     hipLaunchKernelGGL(dcc_gae_kernel, dim3((unsigned)grid), dim3(block), 0, reinterpret_cast<hipStream_t>(stream),
                        rewards, value_preds, masks, denorm, g, gl, returns, advantages, (int)T, (long long)C);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : dcc_fail(-2, std::string("dcc_gae_compute: ") + hipGetErrorString(e));
 }
 
 }  // extern "C"

@@ -10,6 +10,9 @@
 
 #include <cstdint>
 
+#include <string>
+
+#include "dcc_internal.h"
 #include "dcc_mlp.h"
 
 // The Makefile builds the library with -ffp-contract=off for the env kernel's float64 parity; nothing here is
@@ -871,6 +874,10 @@ long long reduce_stage1(float* ws, long long nw, int P, int stride, hipStream_t 
 
 constexpr int kEINVAL = -1, kEHIP = -2, kEUNSUPPORTED = -4;
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+int launch_status(const char* fn) {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : dcc_fail(kEHIP, std::string(fn) + ": " + hipGetErrorString(e));
+}
 
 }  // namespace
 
@@ -890,25 +897,25 @@ DCC_API int64_t dcc_mlp_workspace_floats(int32_t H, int32_t HD) {
 
 DCC_API int dcc_relu_ln_fwd(const float* z, const float* bias, const float* gamma, const float* beta, float eps, float* h,
                             int64_t R, int32_t H, void* stream) {
-    if (!z || !gamma || !beta || !h || R < 0) return kEINVAL;
+    if (!z || !gamma || !beta || !h || R < 0) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     Shape sh;
-    if (!pick_shape(H, sh)) return kEUNSUPPORTED;
-    if (sh.vec == 4 && !(aligned16(z) && aligned16(h) && aligned16(gamma) && aligned16(beta))) return kEINVAL;
+    if (!pick_shape(H, sh)) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (sh.vec == 4 && !(aligned16(z) && aligned16(h) && aligned16(gamma) && aligned16(beta))) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     if (R == 0) return 0;
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
     const int grid = (int)waves_for(R, kReluLnBlocks);
     LAUNCH_SHAPE(relu_ln_fwd_k, grid, 0, z, bias, gamma, beta, eps, h, (long long)R, (int)H);
-    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+    return launch_status(__func__);
 }
 
 DCC_API int dcc_relu_ln_bwd(const float* z, const float* bias, const float* gamma, const float* dh, float eps, float* dz,
                             float* dparams, float* workspace, int64_t R, int32_t H, void* stream) {
-    if (!z || !gamma || !dh || !dz || !dparams || !workspace || R < 1) return kEINVAL;
+    if (!z || !gamma || !dh || !dz || !dparams || !workspace || R < 1) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     Shape sh;
-    if (!pick_shape(H, sh)) return kEUNSUPPORTED;
+    if (!pick_shape(H, sh)) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
     if (sh.vec == 4 && !(aligned16(z) && aligned16(dh) && aligned16(dz) && aligned16(gamma) && aligned16(workspace) &&
                          aligned16(bias)))
-        return kEINVAL;
+        return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
     const int grid = (int)waves_for(R, kReluLnBlocks);
     LAUNCH_SHAPE(relu_ln_bwd_k, grid, 0, z, bias, gamma, dh, eps, dz, workspace, (long long)R, (int)H);
@@ -916,32 +923,32 @@ DCC_API int dcc_relu_ln_bwd(const float* z, const float* bias, const float* gamm
     const long long nseg = reduce_stage1(workspace, (long long)grid * kWavesPerBlock, P, P, st_);
     hipLaunchKernelGGL(reduce_partials_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace, nseg, P,
                        kSegWaves * P, dparams);
-    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+    return launch_status(__func__);
 }
 
 DCC_API int dcc_relu_ln_head_fwd(const float* z, const float* bias, const float* gamma, const float* beta, float eps,
                                  const float* Wo, const float* bo, float* y, int64_t R, int32_t H, int32_t A,
                                  void* stream) {
-    if (!z || !gamma || !beta || !Wo || !y || R < 0) return kEINVAL;
+    if (!z || !gamma || !beta || !Wo || !y || R < 0) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     Shape sh;
-    if (!pick_shape(H, sh) || A < 1 || A > kAMax) return kEUNSUPPORTED;
-    if (sh.vec == 4 && !(aligned16(z) && aligned16(gamma) && aligned16(beta) && aligned16(Wo))) return kEINVAL;
+    if (!pick_shape(H, sh) || A < 1 || A > kAMax) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (sh.vec == 4 && !(aligned16(z) && aligned16(gamma) && aligned16(beta) && aligned16(Wo))) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     if (R == 0) return 0;
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
     const int grid = (int)waves_for(R, kReluLnBlocks);
     LAUNCH_SHAPE(relu_ln_head_fwd_k, grid, 0, z, bias, gamma, beta, eps, Wo, bo, y, (long long)R, (int)H, (int)A);
-    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+    return launch_status(__func__);
 }
 
 DCC_API int dcc_relu_ln_head_bwd(const float* z, const float* bias, const float* gamma, const float* beta, float eps,
                                  const float* Wo, const float* dy, float* dz, float* dparams, float* workspace, int64_t R,
                                  int32_t H, int32_t A, void* stream) {
-    if (!z || !gamma || !beta || !Wo || !dy || !dz || !dparams || !workspace || R < 1) return kEINVAL;
+    if (!z || !gamma || !beta || !Wo || !dy || !dz || !dparams || !workspace || R < 1) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     Shape sh;
-    if (!pick_shape(H, sh) || A < 1 || A > kAMax) return kEUNSUPPORTED;
+    if (!pick_shape(H, sh) || A < 1 || A > kAMax) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
     if (sh.vec == 4 && !(aligned16(z) && aligned16(dz) && aligned16(gamma) && aligned16(beta) && aligned16(Wo) &&
                          aligned16(workspace)))
-        return kEINVAL;
+        return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
     const int grid = (int)waves_for(R, kReluLnBlocks);
     LAUNCH_SHAPE(relu_ln_head_bwd_k, grid, 0, z, bias, gamma, beta, eps, Wo, dy, dz, workspace, (long long)R, (int)H, (int)A);
@@ -949,14 +956,14 @@ DCC_API int dcc_relu_ln_head_bwd(const float* z, const float* bias, const float*
     const long long nseg = reduce_stage1(workspace, (long long)grid * kWavesPerBlock, P, stride, st_);
     hipLaunchKernelGGL(reduce_partials_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace, nseg, P,
                        kSegWaves * stride, dparams);
-    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+    return launch_status(__func__);
 }
 
 DCC_API int dcc_ppo_policy_loss(const float* mean, const float* logstd, const float* actions, const float* old_logp,
                                 const float* adv, const float* active, float clip, float* dmean, float* sums,
                                 float* workspace, int64_t R, int32_t A, int32_t K, void* stream) {
-    if (!mean || !logstd || !actions || !old_logp || !adv || !dmean || !sums || !workspace || R < 1) return kEINVAL;
-    if (A < 1 || A > kAMax || K < 1 || K > kAMax) return kEUNSUPPORTED;
+    if (!mean || !logstd || !actions || !old_logp || !adv || !dmean || !sums || !workspace || R < 1) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
+    if (A < 1 || A > kAMax || K < 1 || K > kAMax) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
     long long blocks = (R + kBlock - 1) / kBlock;
     if (blocks > kReluLnBlocks * 2) blocks = kReluLnBlocks * 2;
@@ -964,13 +971,13 @@ DCC_API int dcc_ppo_policy_loss(const float* mean, const float* logstd, const fl
                        active, clip, dmean, workspace, (long long)R, (int)A, (int)K);
     const long long nseg = reduce_stage1(workspace, blocks, kPpoP, kPpoP, st_);
     hipLaunchKernelGGL(reduce_partials_k, dim3(1), dim3(kBlock), 0, st_, workspace, nseg, kPpoP, kSegWaves * kPpoP, sums);
-    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+    return launch_status(__func__);
 }
 
 DCC_API int dcc_ppo_value_loss(const float* values, const float* value_preds, const float* returns, const float* active,
                                const float* norm, float clip, float delta, int32_t use_clipped, float* dvalues, float* sums,
                                float* workspace, int64_t n, int32_t N, void* stream) {
-    if (!values || !value_preds || !returns || !dvalues || !sums || !workspace || n < 1 || N < 1) return kEINVAL;
+    if (!values || !value_preds || !returns || !dvalues || !sums || !workspace || n < 1 || N < 1) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
     long long blocks = (n + kBlock - 1) / kBlock;
     if (blocks > kReluLnBlocks * 2) blocks = kReluLnBlocks * 2;
@@ -978,42 +985,42 @@ DCC_API int dcc_ppo_value_loss(const float* values, const float* value_preds, co
                        norm, clip, delta, (int)use_clipped, dvalues, workspace, (long long)n, (int)N);
     const long long nseg = reduce_stage1(workspace, blocks, 2, 2, st_);
     hipLaunchKernelGGL(reduce_partials_k, dim3(1), dim3(kBlock), 0, st_, workspace, nseg, 2, kSegWaves * 2, sums);
-    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+    return launch_status(__func__);
 }
 
 DCC_API int dcc_rollout_sample(const float* mean, const float* logstd, const float* eps, const float* value, float* actions,
                                float* logp, float* value_preds, int64_t R, int32_t N, int32_t A, int32_t K, void* stream) {
-    if (!mean || !logstd || !eps || !actions || !logp || R < 1 || N < 1 || (value_preds && !value)) return kEINVAL;
-    if (A < 1 || A > kAMax || K < 1 || K > kAMax) return kEUNSUPPORTED;
+    if (!mean || !logstd || !eps || !actions || !logp || R < 1 || N < 1 || (value_preds && !value)) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
+    if (A < 1 || A > kAMax || K < 1 || K > kAMax) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
     hipLaunchKernelGGL(rollout_sample_k, dim3((unsigned)((R + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), mean, logstd, eps, value, actions, logp, value_preds, (long long)R,
                        (int)N, (int)A, (int)K);
-    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+    return launch_status(__func__);
 }
 
 DCC_API int dcc_rollout_record(const float* reward, const uint8_t* done, float* rewards, float* masks_next, int64_t R,
                                int32_t N, void* stream) {
-    if (!reward || !done || !rewards || !masks_next || R < 1 || N < 1) return kEINVAL;
+    if (!reward || !done || !rewards || !masks_next || R < 1 || N < 1) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     hipLaunchKernelGGL(rollout_record_k, dim3((unsigned)((R + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), reward, done, rewards, masks_next, (long long)R, (int)N);
-    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+    return launch_status(__func__);
 }
 
 DCC_API int dcc_actor_l1_fwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
                              const float* c, const float* gamma, const float* beta, float eps_in, float eps_ln,
                              int32_t D, float* h, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
-    if (!head || !G || !Wh || !s || !c || !gamma || !beta || !h || n < 1 || N < 1 || D < 1) return kEINVAL;
+    if (!head || !G || !Wh || !s || !c || !gamma || !beta || !h || n < 1 || N < 1 || D < 1) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     Shape sh;
-    if (!pick_shape(H, sh) || HD < 1 || HD > 64 || pad_hd(HD) < 0) return kEUNSUPPORTED;
+    if (!pick_shape(H, sh) || HD < 1 || HD > 64 || pad_hd(HD) < 0) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
     const size_t lds = (size_t)HD * H * sizeof(float);
-    if (lds > 64 * 1024) return kEUNSUPPORTED;
+    if (lds > 64 * 1024) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
     if (sh.vec == 4 && !(aligned16(G) && aligned16(h) && aligned16(gamma) && aligned16(beta) && aligned16(s) && aligned16(c)))
-        return kEINVAL;
+        return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
     const int grid = (int)waves_for(n, kL1Blocks * 2);
     LAUNCH_SHAPE(actor_l1_fwd_k, grid, lds, head, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, (int)D, h,
                  (long long)n, (int)N, (int)HD, (int)H);
-    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+    return launch_status(__func__);
 }
 
 DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
@@ -1022,21 +1029,21 @@ DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* st
                              float* workspace, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
     if (!head || !G || !Wh || !s || !c || !gamma || !dh || !dG || (!dWh && !dq) || !ds || !dc || !dgamma || !dbeta ||
         !workspace || n < 1 || N < 1 || D < 1)
-        return kEINVAL;
+        return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     Shape sh;
     const int hdp = pad_hd(HD);
-    if (!pick_shape(H, sh) || HD < 1 || HD > 64 || hdp < 0) return kEUNSUPPORTED;
+    if (!pick_shape(H, sh) || HD < 1 || HD > 64 || hdp < 0) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
     const size_t lds = (size_t)HD * H * sizeof(float);
-    if (lds > 64 * 1024) return kEUNSUPPORTED;
+    if (lds > 64 * 1024) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
     if (sh.vec == 4 && !(aligned16(G) && aligned16(dh) && aligned16(dG) && aligned16(gamma) && aligned16(s) &&
                          aligned16(c) && aligned16(workspace)))
-        return kEINVAL;
+        return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
     const int grid = (int)waves_for(n, kL1Blocks);
     int hdp_used = hdp;
     int grid_used = grid;
     if (dq) {   // two-kernel variant: light registers -> full occupancy, so use the larger grid too
-        if (sh.vec == 4 && !aligned16(dq)) return kEINVAL;
+        if (sh.vec == 4 && !aligned16(dq)) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
         grid_used = (int)waves_for(n, kL1Blocks * 2);
         launch_l1_bwd<0>(sh, grid_used, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H);
     } else {
@@ -1052,7 +1059,7 @@ DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* st
     const long long nseg = reduce_stage1(workspace, (long long)grid_used * kWavesPerBlock, P, P, st_);
     hipLaunchKernelGGL(l1_reduce_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace, nseg,
                        (long long)kSegWaves * P, hdp_used, (int)HD, (int)H, dWh, ds, dc, dgamma, dbeta);
-    return hipGetLastError() == hipSuccess ? 0 : kEHIP;
+    return launch_status(__func__);
 }
 
 }  // extern "C"

@@ -44,7 +44,8 @@ EXPORTS = ["dcc_obs_expand", "dcc_gae_compute", "dcc_abi_version", "dcc_last_err
            "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout", "dcc_env_get_state",
            "dcc_env_set_state", "dcc_env_bytes_per_step", "dcc_obs_features",
            "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_relu_ln_head_fwd", "dcc_relu_ln_head_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd", "dcc_ppo_policy_loss",
-           "dcc_rollout_sample", "dcc_rollout_record", "dcc_ppo_value_loss"]
+           "dcc_rollout_sample", "dcc_rollout_record", "dcc_ppo_value_loss",
+           "dcc_grad_norm_workspace_floats", "dcc_grad_norm_clip", "dcc_adam_step"]
 
 _lib = None
 
@@ -91,6 +92,10 @@ def load_library(path=None):
     L.dcc_mlp_workspace_floats.restype = i64
     L.dcc_actor_l1_fwd.argtypes = [_vp] * 8 + [f32, f32, i32, _vp, i64, i32, i32, i32, _vp]
     L.dcc_actor_l1_bwd.argtypes = [_vp] * 8 + [f32, f32, i32] + [_vp] * 8 + [i64, i32, i32, i32, _vp]
+    L.dcc_grad_norm_workspace_floats.argtypes = [i64]
+    L.dcc_grad_norm_workspace_floats.restype = i64
+    L.dcc_grad_norm_clip.argtypes = [_vp, i64, f32, _vp, _vp, _vp]
+    L.dcc_adam_step.argtypes = [_vp, _vp, _vp, _vp, i64, f32, f32, f32, f32, f32, f32, _vp, _vp]
     if L.dcc_abi_version() != 2:
         raise DccError("libdcc_hip.so ABI version %d != 2" % L.dcc_abi_version())
     _lib = L
@@ -333,8 +338,7 @@ def gae_compute(rewards, value_preds, masks, denorm, gamma, gae_lambda, returns,
     with torch.cuda.device(rewards.device):
         rc = L.dcc_gae_compute(_ptr(rewards), _ptr(value_preds), _ptr(masks), _ptr(denorm), float(gamma),
                                float(gae_lambda), _ptr(returns), _ptr(advantages), T, C, _stream())
-    if rc != 0:
-        raise DccError("dcc_gae_compute failed (%d)" % rc)
+    _check(rc, "dcc_gae_compute")
     return returns
 
 
@@ -497,3 +501,27 @@ def actor_l1_bwd(head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, D, two_ker
         else:
             dWh = dq.t() @ hf
     return dG, dWh, vecs[0], vecs[1], vecs[2], vecs[3]
+
+
+# ---- fused optimizer step on flat storage (include/dcc_optim.h) ------------------------------------------------------
+def grad_norm_workspace_floats(n):
+    return int(load_library().dcc_grad_norm_workspace_floats(int(n)))
+
+
+def grad_norm_clip(flat_grad, max_norm, out, workspace):
+    """out [2] <- {||flat_grad||_2, min(1, max_norm / (norm + 1e-6))} (max_norm <= 0: coefficient 1)."""
+    _f32c(flat_grad, "flat_grad"); _f32c(out, "out"); _f32c(workspace, "workspace")
+    with torch.cuda.device(flat_grad.device):
+        _check(load_library().dcc_grad_norm_clip(_ptr(flat_grad), flat_grad.numel(), float(max_norm), _ptr(out), _ptr(workspace),
+                                                 _stream()), "dcc_grad_norm_clip")
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, clip=None):
+    for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _f32c(t, nm)
+        if t.numel() != param.numel():
+            raise ValueError("adam_step: %s has %d elements, param %d" % (nm, t.numel(), param.numel()))
+    with torch.cuda.device(param.device):
+        _check(load_library().dcc_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(step_size),
+                                            float(bc2_sqrt), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                            _ptr(clip), _stream()), "dcc_adam_step")

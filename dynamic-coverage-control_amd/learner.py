@@ -43,7 +43,7 @@ def _to_namespace(cfg):
 class Learner:
     def __init__(self, cfg):
         self.cfg = _to_namespace(cfg)
-        for k, v in (("double_surrogate", True), ("dedup_critic", True), ("use_hip_graph", False), ("amp_bf16", False)):
+        for k, v in (("double_surrogate", True), ("dedup_critic", True), ("use_hip_graph", False)):
             if not hasattr(self.cfg, k):
                 setattr(self.cfg, k, v)
         self.recurrent = bool(self.cfg.use_recurrent_policy or self.cfg.use_naive_recurrent_policy)
@@ -81,9 +81,6 @@ class Learner:
             self.policy.enable_structured_input(ObsLayout(env.n_agents, env.n_pois, env.poi_xy, env.env.m_energy))
         self.policy.broadcast_parameters(0)
         self.trainer = MAPPOTrainer(cfg=self.cfg, policy=self.policy)
-        if self.trainer.amp_bf16 and self.rank == 0:
-            print("amp_bf16: bf16 autocast bypasses the fused fp32 trunk / loss kernels and is SLOWER than the default fp32 "
-                  "path on this build (config 3: 2.9 vs 8.4 M agent-env-steps/s); kept for A/B against the torch formulation")
 
         # 3. buffers (sized for the LOCAL env shard)
         self.rl_buffer = self._make_buffer(self.train_envs)
@@ -99,30 +96,27 @@ class Learner:
         self.n_iters = self.cfg.n_iters
         self.eval_interval, self.log_interval = self.cfg.eval_interval, self.cfg.log_interval
         self.is_save_model, self.save_interval = self.cfg.save_model, self.cfg.save_interval
+        self.start_iter, self.cur_iter = 1, 0
+        self.total_env_steps = 0
         if getattr(self.cfg, "load_model", False):
             self.load_model(self.cfg.load_model_path)
         self.expt_name = datetime.datetime.now().strftime("%m%d_%H%M_") + "sd{}".format(self.cfg.seed)
+        self.output_path = str(os.path.join(self.cfg.main_save_path, self.cfg.save_name, self.expt_name))
         if self.is_save_model and self.rank == 0:
-            self.output_path = str(os.path.join(self.cfg.main_save_path, self.cfg.save_name, self.expt_name))
             self.cfg.output_path = self.output_path
             os.makedirs(self.output_path, exist_ok=True)
             with open(os.path.join(self.output_path, "config.json"), "w") as f:
                 json.dump({k: v for k, v in vars(self.cfg).items()}, f, indent=4, default=str)
         self._start_time = self._check_time = time.time()
-        self.total_env_steps = 0
         # cfg.use_hip_graph: after one eager pass each (buffer, envs) pair is captured into a hipGraph and
         # replayed (parameters are updated in place, so the graph always sees the current policy; the
         # sampling RNG is graph-safe).  The ~40 small kernels of a step are launch-bound when issued from
         # Python: config 3 rollout 0.13 s eager -> 0.06 s replayed, bit-identical results.
-        self.start_iter, self.cur_iter = 1, 0
+        # The captured body holds NO reduction: the logged statistics are accumulated element-wise per env inside the
+        # graph (reward sum, running max of the coverage rate) and reduced over the envs after the replay, outside capture
+        # (multi-block torch reductions inside a replayed graph are not reliable on this stack: tools/graph_reduce_probe.py).
         self._graphs = {}
-        self.use_hip_graph = bool(self.cfg.use_hip_graph) and ptu.device.type == "cuda"
-        if self.use_hip_graph and self.train_envs.n_envs > 32768:
-            # the rollout's torch reductions run over the E per-env rewards; multi-block reductions inside a replayed
-            # graph are not reliable on this stack (tools/graph_reduce_probe.py: wrong from 131 k elements, fine at 32 k)
-            if self.rank == 0:
-                print("use_hip_graph disabled: %d envs per GPU exceeds the verified range" % self.train_envs.n_envs)
-            self.use_hip_graph = False
+        self.use_hip_graph = bool(self.cfg.use_hip_graph) and ptu.device.type == "cuda" and not self.recurrent
 
     def _make_buffer(self, envs):
         bcfg = copy.deepcopy(self.cfg)
@@ -148,10 +142,11 @@ class Learner:
             if iter_ % self.log_interval == 0:
                 self.log(iter_=iter_, rollout_info=rollout_info, rl_train_info=rl_train_info,
                          test_rollout_info=test_rollout_info)
-            if self.is_save_model and self.rank == 0 and iter_ % self.save_interval == 0:
+            if self.is_save_model and iter_ % self.save_interval == 0:      # collective: every rank contributes its RNG / env shard
                 save_path = os.path.join(self.output_path, "models_%d.pt" % iter_)
                 self.save_model(save_path)
-                print("model saved in %s" % save_path)
+                if self.rank == 0:
+                    print("model saved in %s" % save_path)
         self.train_envs.close()
         if self.test_envs is not None:
             self.test_envs.close()
@@ -161,7 +156,7 @@ class Learner:
     def _rollout_body(self, r_buffer, r_envs):
         """warmup + T x (collect -> env step -> insert) + compute, all asynchronous on the current stream."""
         self.warmup(r_buffer, r_envs)
-        rew_sum = torch.zeros((), dtype=torch.float64, device=ptu.device)
+        rew_acc = torch.zeros(r_envs.n_envs, dtype=torch.float64, device=ptu.device)    # per env: element-wise only
         cov_max = torch.zeros(r_envs.n_envs, dtype=torch.float32, device=ptu.device)
         fused_glue = self._fused_glue_ok(r_buffer)
         for cur_step in range(self.max_ep_len):
@@ -183,10 +178,10 @@ class Learner:
                 r_buffer.step = (cur_step + 1) % r_buffer.episode_length
             else:
                 self.insert((out, values, actions, action_log_probs, rnn_a, rnn_c), r_buffer)
-            rew_sum += out["reward"].double().mean()
+            rew_acc += out["reward"]
             cov_max = torch.maximum(cov_max, out["coverage"])
         self.compute(r_buffer)
-        return torch.stack([rew_sum, cov_max.double().mean()])
+        return rew_acc, cov_max
 
     @torch.no_grad()
     def rollout(self, r_buffer, r_envs, is_render=False, iter_=0):
@@ -214,8 +209,10 @@ class Learner:
                         print("hipGraph capture of the rollout failed (%s); continuing eagerly" % e)
                     self.use_hip_graph = False
                     torch.cuda.synchronize()
-        self.total_env_steps += self.max_ep_len * r_envs.n_envs * self.world
-        stats = stats.clone()
+        if r_envs is self.train_envs:      # the logged throughput counts training env steps only (not eval rollouts)
+            self.total_env_steps += self.max_ep_len * r_envs.n_envs * self.world
+        rew_acc, cov_max = stats           # reduced over the envs HERE, outside any captured graph
+        stats = torch.stack([rew_acc.mean(), cov_max.double().mean()])
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(stats)
@@ -238,10 +235,9 @@ class Learner:
         E, N = r_buffer.n_rollout_threads, self.n_agents
         if r_buffer.structured:     # compact features of the current state: no observation rows anywhere
             feats = r_buffer.features_at(cur_step)
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.trainer.amp_bf16):
-                actions, logp, _ = self.policy.actor(feats)
-                values = self.policy.critic(feats)[0].view(E, 1, 1).expand(E, N, 1)
-            return values.float(), actions.float().view(E, N, -1).contiguous(), logp.float().view(E, N, 1)
+            actions, logp, _ = self.policy.actor(feats)
+            values = self.policy.critic(feats)[0].view(E, 1, 1).expand(E, N, 1)
+            return values, actions.view(E, N, -1).contiguous(), logp.view(E, N, 1)
         obs = r_buffer.obs_at(cur_step).view(E * N, -1)
         if self.recurrent:          # learner.py:231-252 with the GRU states and masks of this step, one critic row per agent
             masks = r_buffer.masks[cur_step].reshape(E * N, 1)
@@ -250,18 +246,17 @@ class Learner:
                                                r_buffer.rnn_states_critic[cur_step].reshape(E * N, *r_buffer.rnn_states.shape[3:]), masks)
             return (values.view(E, N, 1), actions.view(E, N, -1).contiguous(), logp.view(E, N, 1),
                     rnn_a.reshape(E, N, *rnn_a.shape[1:]), rnn_c.reshape(E, N, *rnn_c.shape[1:]))
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.trainer.amp_bf16):
-            actions, logp, _ = self.policy.actor(obs)
-            if self.trainer.dedup_critic:
-                values = self.policy.critic(r_buffer.share_obs_env_at(cur_step))[0].view(E, 1, 1).expand(E, N, 1)
-            else:
-                so = r_buffer.share_obs_env_at(cur_step).unsqueeze(1).expand(E, N, -1)
-                values = self.policy.critic(so.reshape(E * N, -1))[0].view(E, N, 1)
-        return values.float(), actions.float().view(E, N, -1).contiguous(), logp.float().view(E, N, 1)
+        actions, logp, _ = self.policy.actor(obs)
+        if self.trainer.dedup_critic:
+            values = self.policy.critic(r_buffer.share_obs_env_at(cur_step))[0].view(E, 1, 1).expand(E, N, 1)
+        else:
+            so = r_buffer.share_obs_env_at(cur_step).unsqueeze(1).expand(E, N, -1)
+            values = self.policy.critic(so.reshape(E * N, -1))[0].view(E, N, 1)
+        return values, actions.view(E, N, -1).contiguous(), logp.view(E, N, 1)
 
     def _fused_glue_ok(self, r_buffer):
         from algos.algo_utils import fused
-        return (ptu.device.type == "cuda" and fused.ENABLED and self.trainer.dedup_critic and not self.trainer.amp_bf16
+        return (ptu.device.type == "cuda" and fused.ENABLED and self.trainer.dedup_critic
                 and r_buffer.act_dim <= fused.HEAD_MAX_OUT and not self.recurrent)
 
     @torch.no_grad()
@@ -332,42 +327,64 @@ class Learner:
         self._check_time = now
 
     def save_model(self, save_path):
-        self.trainer.save_model(save_path)
+        """<save_path>/agent.pkl (the reference's file name, parameters only) + <save_path>/resume.pt (full state)."""
+        if self.rank == 0:
+            self.trainer.save_model(save_path)
         self.save_checkpoint(os.path.join(save_path, "resume.pt"))
 
     # ---- faithful resume (SURVEY.md 8f row 2) ------------------------------------------------------------
+    def _rank_state(self):
+        """What differs between the ranks of a multi-GPU job: the RNG streams (seeded seed + rank) and the env shard."""
+        return {"rng_torch": torch.get_rng_state(), "rng_numpy": np.random.get_state(),
+                "rng_cuda": torch.cuda.get_rng_state(ptu.device) if ptu.device.type == "cuda" else None,
+                "env_state": {k: v.cpu() for k, v in self.train_envs.env.get_state().items()}}
+
     def save_checkpoint(self, path):
         """Everything needed to continue a run bit-for-bit: parameters, both Adam states, ValueNorm, the
-        iteration counter, RNG streams and the env state.  (The reference pickles the policy object only:
+        iteration counter, and PER RANK the RNG streams and the env-shard state (gathered to rank 0, which writes the
+        file; COLLECTIVE in a multi-GPU job: every rank must call it).  (The reference pickles the policy object only:
         ValueNorm, iteration and RNG are lost, uav_dcc_control/algos/mappo.py:237-247.)"""
+        ranks = [self._rank_state()]
+        if self.world > 1:
+            import torch.distributed as dist
+            gathered = [None] * self.world if self.rank == 0 else None
+            dist.gather_object(ranks[0], gathered, dst=0)
+            ranks = gathered
+        if self.rank != 0:
+            return
         cpu = lambda d: {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in d.items()}
-        ck = {"format": 1, "iter": self.cur_iter, "total_env_steps": self.total_env_steps,
+        ck = {"format": 2, "iter": self.cur_iter, "total_env_steps": self.total_env_steps, "world_size": self.world,
               "actor": cpu(self.policy.actor.state_dict()), "critic": cpu(self.policy.critic.state_dict()),
               "actor_optimizer": self.policy.actor_optimizer.state_dict(),
               "critic_optimizer": self.policy.critic_optimizer.state_dict(),
               "value_normalizer": cpu(self.trainer.value_normalizer.state_dict()) if self.trainer.value_normalizer is not None else None,
-              "rng_torch": torch.get_rng_state(), "rng_numpy": np.random.get_state(),
-              "rng_cuda": torch.cuda.get_rng_state(ptu.device) if ptu.device.type == "cuda" else None,
-              "env_state": {k: v.cpu() for k, v in self.train_envs.env.get_state().items()}}
+              "ranks": ranks}
         torch.save(ck, path)
 
     def load_checkpoint(self, path):
+        """Every rank reads the file and takes ITS OWN RNG streams and env shard (the replicated parts -- parameters,
+        optimizer moments, ValueNorm, counters -- are identical on all ranks by construction)."""
         ck = torch.load(path, map_location="cpu", weights_only=False)
+        if ck.get("format", 1) == 1:        # single-rank layout of the first format
+            ck["ranks"] = [{k: ck[k] for k in ("rng_torch", "rng_numpy", "rng_cuda", "env_state")}]
+            ck["world_size"] = 1
+        if ck["world_size"] != self.world:
+            raise ValueError("checkpoint written by %d ranks, this job has %d (the env shards and RNG streams are per rank)"
+                             % (ck["world_size"], self.world))
         self.policy.actor.load_state_dict(ck["actor"]); self.policy.critic.load_state_dict(ck["critic"])
         self.policy.actor_optimizer.load_state_dict(ck["actor_optimizer"])
         self.policy.critic_optimizer.load_state_dict(ck["critic_optimizer"])
-        if getattr(self.policy, "capturable", False):     # capturable Adam: the learning rate lives on the device
-            for opt in (self.policy.actor_optimizer, self.policy.critic_optimizer):
-                for g in opt.param_groups:
-                    g["lr"] = torch.as_tensor(float(g["lr"]), dtype=torch.float32, device=ptu.device)
         if ck["value_normalizer"] is not None and self.trainer.value_normalizer is not None:
             self.trainer.value_normalizer.load_state_dict(ck["value_normalizer"])
-        torch.set_rng_state(ck["rng_torch"]); np.random.set_state(ck["rng_numpy"])
-        if ck["rng_cuda"] is not None and ptu.device.type == "cuda":
-            torch.cuda.set_rng_state(ck["rng_cuda"], ptu.device)
-        self.train_envs.env.set_state(**ck["env_state"])
+        mine = ck["ranks"][self.rank]
+        torch.set_rng_state(mine["rng_torch"]); np.random.set_state(mine["rng_numpy"])
+        if mine["rng_cuda"] is not None and ptu.device.type == "cuda":
+            torch.cuda.set_rng_state(mine["rng_cuda"], ptu.device)
+        self.train_envs.env.set_state(**mine["env_state"])
         self.cur_iter, self.start_iter = ck["iter"], ck["iter"] + 1
         self.total_env_steps = ck["total_env_steps"]
+        from algos.algo_utils.structured import invalidate_folded_weights
+        invalidate_folded_weights(self.policy.actor, self.policy.critic)
 
     # ---- headless evaluation (SURVEY.md 8f row 3) ---------------------------------------------------------
     @torch.no_grad()
@@ -409,4 +426,11 @@ class Learner:
         return res
 
     def load_model(self, load_path):
-        self.trainer.load_model(load_path)
+        """cfg.load_model / cfg.load_model_path (expt.yaml, like the reference): a directory written by save_model.  When
+        it holds resume.pt the run CONTINUES from it (iteration counter, lr schedule, optimizer moments, ValueNorm, RNG,
+        env state); with agent.pkl alone -- also one written by the reference -- only the parameters are taken."""
+        resume = os.path.join(load_path, "resume.pt")
+        if os.path.exists(resume):
+            self.load_checkpoint(resume)
+        else:
+            self.trainer.load_model(load_path)

@@ -32,10 +32,7 @@ def update_linear_schedule(optimizer, epoch, total_num_epochs, initial_lr):
     """lr = lr0 * (1 - epoch/total), floored at 0 (util.py:29-33)."""
     lr = max(initial_lr - (initial_lr * (epoch / float(total_num_epochs))), 0.0)
     for g in optimizer.param_groups:
-        if torch.is_tensor(g["lr"]):      # capturable Adam keeps its learning rate on the device (hipGraph-replayed epochs)
-            g["lr"].fill_(lr)
-        else:
-            g["lr"] = lr
+        g["lr"] = lr
 
 
 def huber_loss(e, d):

@@ -74,7 +74,7 @@ def test_learner_runs_and_improves_nothing_breaks(tmp_path):
     # rollout invariants on the device buffer
     b = lr.rl_buffer
     assert b.compact and b.structured and b.obs is None       # shipped default: compact env state, no observation rows
-    assert torch.isfinite(b.returns).all() and torch.isfinite(b.state_pos).all() and torch.isfinite(b.obs_rows(0, 21)).all()
+    assert torch.isfinite(b.returns).all() and torch.isfinite(b.state_pos).all() and torch.isfinite(b.state_energy).all()
     assert bool(((b.masks == 0) | (b.masks == 1)).all())
     # values identical across the agents of an env (centralised critic evaluated once per env)
     assert float((b.value_preds - b.value_preds[:, :, :1]).abs().max()) == 0.0
@@ -193,21 +193,28 @@ def test_graph_replay_does_not_reuse_stale_features():
     ptu.set_gpu_mode(False)
 
 
-@pytest.mark.parametrize("opt", ["use_hip_graph", "amp_bf16"])
-def test_optional_fast_paths_run(opt):
-    """The two optional switches (hipGraph-captured rollout, bf16 autocast of the policy GEMMs) stay healthy."""
+def test_hip_graph_rollout_equals_the_eager_rollout():
+    """use_hip_graph (default on): the captured rollout holds no reduction -- per-env reward sums / coverage maxima are
+    accumulated element-wise inside the graph and reduced after the replay -- and a replay fills the buffer and returns
+    the statistics exactly like the same rollout issued eagerly from the same RNG state."""
     import utils.pytorch_utils as ptu
     ptu.set_gpu_mode(True, 0)
     from learner import Learner
-    lr = Learner(_cfg(n_rollout_threads=32, n_eval_rollout_threads=0, num_agents=4, num_pois=16, max_ep_len=12, n_iters=1,
-                      ppo_epoch=2, algo_hidden_size=32, save_model=False, **{opt: True}))
-    r_eager = lr.rollout(lr.rl_buffer, lr.train_envs)        # eager pass (+ capture when use_hip_graph)
-    r_again = lr.rollout(lr.rl_buffer, lr.train_envs)        # graph replay when use_hip_graph
-    info = lr.rl_update()
-    assert all(np.isfinite(v) for v in info.values()) and np.isfinite(r_again["reward"])
-    if opt == "use_hip_graph":
-        assert lr.use_hip_graph and len(lr._graphs) == 1, "capture must have succeeded on the GPU box"
-        assert torch.isfinite(lr.rl_buffer.returns).all()
+    kw = dict(n_rollout_threads=32, n_eval_rollout_threads=0, num_agents=4, num_pois=16, max_ep_len=12, n_iters=1,
+              ppo_epoch=2, algo_hidden_size=32, save_model=False, seed=17)
+    g, e = Learner(_cfg(**dict(kw, use_hip_graph=True))), Learner(_cfg(**dict(kw, use_hip_graph=False)))
+    torch.manual_seed(5); g.rollout(g.rl_buffer, g.train_envs)            # eager pass + capture
+    assert g.use_hip_graph and len(g._graphs) == 1, "capture must have succeeded on the GPU box"
+    for it in range(3):
+        st = torch.cuda.get_rng_state()
+        r_replay = g.rollout(g.rl_buffer, g.train_envs)                   # graph replay
+        torch.cuda.set_rng_state(st)
+        r_eager = e.rollout(e.rl_buffer, e.train_envs)
+        assert r_replay == r_eager, it
+        for name in ("actions", "rewards", "masks", "value_preds", "returns", "state_pos"):
+            assert torch.equal(getattr(g.rl_buffer, name), getattr(e.rl_buffer, name)), (name, it)
+        ig, ie = g.rl_update(), e.rl_update()
+        assert ig == ie and all(np.isfinite(v) for v in ig.values())
     ptu.set_gpu_mode(False)
 
 
@@ -336,36 +343,80 @@ def test_structured_learner_full_train_loop_with_eval_envs(tmp_path):
     ptu.set_gpu_mode(False)
 
 
-def test_capturable_adam_plumbing_of_the_experimental_epoch_graph():
-    """use_hip_graph_update is experimental and off (replayed graphs with large torch reductions are unreliable on this
-    stack: tools/graph_reduce_probe.py; a 400-iteration soak of whole-epoch replay diverged from eager epochs).  What is
-    tested is the deterministic plumbing around it: capturable Adam with a device-resident learning rate follows the
-    linear schedule, survives a checkpoint round trip, and -- with the epochs issued eagerly -- trains like the
-    default optimizer up to the float32 bias-correction rounding."""
-    import utils.pytorch_utils as ptu
-    ptu.set_gpu_mode(True, 0)
-    from learner import Learner
-    kw = dict(n_rollout_threads=24, n_eval_rollout_threads=0, num_agents=4, num_pois=20, max_ep_len=20, n_iters=3,
-              ppo_epoch=4, algo_hidden_size=64, save_model=False, seed=13)
-    c = Learner(_cfg(**dict(kw, use_hip_graph_update=True)))
-    c.trainer.graph_update = False                     # capturable optimizers, epochs issued eagerly
-    d = Learner(_cfg(**kw))                            # default optimizers
-    assert c.policy.capturable and torch.is_tensor(c.policy.actor_optimizer.param_groups[0]["lr"]) and not d.policy.capturable
-    for it in (1, 2, 3):
-        for lr in (c, d):
-            lr.policy.lr_decay(it, 3)
-            torch.manual_seed(100 + it)
-            lr.rollout(lr.rl_buffer, lr.train_envs)
-        ic, idf = c.rl_update(), d.rl_update()
-        if it == 1:                                    # same data in iteration 1: same losses, parameters within rounding
-            for k in ic:
-                np.testing.assert_allclose(ic[k], idf[k], rtol=1e-4, atol=1e-6, err_msg=k)
-            for (k, a), (_, b) in zip(c.policy.actor.state_dict().items(), d.policy.actor.state_dict().items()):
-                np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
-        assert all(np.isfinite(v) for v in ic.values())
-    assert float(c.policy.actor_optimizer.param_groups[0]["lr"]) == 0.0        # lr0 * (1 - 3/3), filled on the device
-    assert len(c.trainer._epoch_graphs) == 0
-    ptu.set_gpu_mode(False)
+def test_flat_adam_matches_torch_adam_and_clip_grad_norm():
+    """algo_utils/optim.py on the GPU (dcc_grad_norm_clip + dcc_adam_step, include/dcc_optim.h) against
+    nn.utils.clip_grad_norm_ + torch.optim.Adam on the same gradients: norms, parameters and moments over 5 steps, with
+    the clip active and inactive, odd parameter sizes (tails that are not a multiple of 4), weight decay, and run-to-run
+    bit equality."""
+    from algos.algo_utils.optim import FlatAdam
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(2)
+    shapes = [(64, 37), (64,), (3, 5), (1,), (130, 64), (7,)]
+
+    def run(max_norm, wd, gscale):
+        ps = [torch.nn.Parameter(torch.randn(*sh, device=dev)) for sh in shapes]
+        qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        flat = FlatAdam(ps, lr=5e-4, eps=1e-5, weight_decay=wd)
+        ref = torch.optim.Adam(qs, lr=5e-4, eps=1e-5, weight_decay=wd)
+        norms = []
+        for step in range(5):
+            flat.zero_grad()
+            gs = [torch.randn(*sh, device=dev) * gscale for sh in shapes]
+            for p, q, g in zip(ps, qs, gs):
+                p.grad.add_(g)                    # what autograd does with a pre-existing .grad
+                q.grad = g.clone()
+            rn = torch.nn.utils.clip_grad_norm_(qs, max_norm) if max_norm else torch.linalg.vector_norm(torch.cat([g.reshape(-1) for g in gs]))
+            ref.step()
+            n = flat.clip_and_step(max_norm)
+            norms.append(float(n))
+            np.testing.assert_allclose(float(n), float(rn), rtol=2e-6)
+            for p, q in zip(ps, qs):
+                np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=2e-8)
+        for i, (p, off) in enumerate(zip(ps, flat._offsets)):
+            st = ref.state[qs[i]]
+            np.testing.assert_allclose(flat.exp_avg[off:off + p.numel()].cpu().numpy(), st["exp_avg"].reshape(-1).cpu().numpy(), rtol=2e-6, atol=1e-9)
+            np.testing.assert_allclose(flat.exp_avg_sq[off:off + p.numel()].cpu().numpy(), st["exp_avg_sq"].reshape(-1).cpu().numpy(), rtol=2e-6, atol=1e-12)
+        assert all(p.data_ptr() % 256 == 0 for p in ps) and float(flat.flat_param[shapes[0][0] * shapes[0][1]:64 * 38].abs().sum()) == 0.0
+        return norms, flat.flat_param.clone()
+
+    for max_norm, wd, gscale in ((10.0, 0.0, 1.0), (10.0, 0.0, 0.01), (None, 0.0, 1.0), (0.5, 0.01, 3.0)):
+        torch.manual_seed(9); n1, p1 = run(max_norm, wd, gscale)
+        torch.manual_seed(9); n2, p2 = run(max_norm, wd, gscale)
+        assert n1 == n2 and torch.equal(p1, p2)               # fixed-order reduction: bit-reproducible
+    # checkpoint round trip, and taking over a torch.optim.Adam state_dict
+    ps = [torch.nn.Parameter(torch.randn(5, 3, device=dev)), torch.nn.Parameter(torch.randn(9, device=dev))]
+    a = FlatAdam(ps, lr=1e-3)
+    for p in ps:
+        p.grad.add_(torch.randn_like(p))
+    a.clip_and_step(1.0)
+    b = FlatAdam([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=7.0)
+    b.load_state_dict(a.state_dict())
+    assert b.step_count == 1 and torch.equal(a.exp_avg, b.exp_avg) and b.param_groups[0]["lr"] == 1e-3
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    t = torch.optim.Adam(qs, lr=2e-3)
+    for q in qs:
+        q.grad = torch.ones_like(q)
+    t.step()
+    b.load_state_dict(t.state_dict())
+    assert b.step_count == 1 and b.param_groups[0]["lr"] == 2e-3 and float(b.exp_avg[:15].min()) > 0
+
+
+def test_entry_points_report_through_dcc_last_error():
+    """dcc_gae_compute / dcc_mlp.h / dcc_optim.h failures carry a message (round-1 verdict: they returned a bare -1)."""
+    import dcc_hip
+    L = dcc_hip.load_library()
+    assert L.dcc_gae_compute(None, None, None, None, 0.99, 0.95, None, None, 4, 4, None) != 0
+    assert b"dcc_gae_compute" in L.dcc_last_error()
+    assert L.dcc_relu_ln_fwd(None, None, None, None, 1e-5, None, 4, 256, None) != 0
+    assert b"dcc_relu_ln_fwd" in L.dcc_last_error()
+    x = torch.zeros(8, 7, device="cuda")
+    assert L.dcc_relu_ln_fwd(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), 1e-5, x.data_ptr(), 8, 1000, None) == -4
+    assert b"compiled variants" in L.dcc_last_error()
+    assert L.dcc_adam_step(None, None, None, None, 4, 0.1, 1.0, 0.9, 0.999, 1e-8, 0.0, None, None) != 0
+    assert b"dcc_adam_step" in L.dcc_last_error()
+    with pytest.raises(dcc_hip.DccError, match="dcc_gae_compute"):
+        dcc_hip.gae_compute(torch.zeros(0, 4, device="cuda"), torch.zeros(1, 4, device="cuda"), torch.zeros(1, 4, device="cuda"),
+                            None, 0.99, 0.95, torch.zeros(1, 4, device="cuda"))
 
 
 def test_fused_rollout_glue_fills_the_buffer_like_collect_and_insert():

@@ -316,3 +316,44 @@ def test_compact_buffer_slots_and_guards():
     plain = _filled_buffer(cfg)
     assert plain.obs_slot(3).data_ptr() == plain.obs[3].data_ptr() and plain.state_slot(3) == {}
     assert plain.share_obs_env_at(2).data_ptr() == plain.obs[2].data_ptr()
+
+
+def test_load_model_accepts_a_checkpoint_written_by_the_reference():
+    """tests/golden/ref_agent_small/agent.pkl was written by the reference's MAPPOTrainer.save_model (a pickle of its
+    MAPPOPolicy object, tools/gen_golden_ref_checkpoint.py; same seed as mappo_small.npz).  load_model takes over the
+    parameters (dropping the dead mlp.fc_h template) although classes the pickle mentions do not exist here."""
+    pol, tr = _policy(make_cfg())
+    for p in list(pol.actor.parameters()) + list(pol.critic.parameters()):
+        p.data.add_(1.0)                                        # make sure values really come from the file
+    tr.load_model(os.path.join(GOLDEN, "ref_agent_small"))
+    for name, net in (("actor/", pol.actor), ("critic/", pol.critic)):
+        for k, v in net.state_dict().items():
+            np.testing.assert_array_equal(v.numpy(), Z[name + k], err_msg=k)
+    # parameters are still the views of the flat optimizer storage (the load copies in place)
+    opt = pol.actor_optimizer
+    assert all(p.data_ptr() == opt.flat_param.data_ptr() + 4 * off for p, off in zip(opt._params, opt._offsets))
+    # round trip through this package's own format
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        tr.save_model(d)
+        pol2, tr2 = _policy(make_cfg())
+        pol2.actor.act.action_out.logstd._bias.data.fill_(3.0)
+        tr2.load_model(d)
+        assert float(pol2.actor.act.action_out.logstd._bias.abs().sum()) == 0.0
+
+
+def test_double_surrogate_false_uses_one_log_prob_column():
+    """cfg.double_surrogate (advisor finding: the flag used to be dead).  With one column the policy surrogate -- and its
+    gradient -- is half the reference's doubled one; value loss and entropy are untouched."""
+    out = {}
+    for flag in (True, False):
+        pol, tr = _policy(make_cfg(double_surrogate=flag, ppo_epoch=1))
+        buf = _filled_buffer(make_cfg())
+        _set_vn(tr.value_normalizer, "vn0")
+        adv = torch.from_numpy(Z["adv_norm"])
+        sample = next(buf.feed_forward_generator(adv, 1, dedup_critic=True))
+        pl, ent, vl, imp = tr._forward_losses(sample)
+        out[flag] = (float(pl), float(ent), float(vl), tuple(imp.shape))
+    assert out[True][3][1] == 2 and out[False][3][1] == 1
+    np.testing.assert_allclose(out[False][0], 0.5 * out[True][0], rtol=1e-6)
+    assert out[False][1] == out[True][1] and out[False][2] == out[True][2]

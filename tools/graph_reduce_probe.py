@@ -1,7 +1,8 @@
 """Stand-alone PyTorch-only probe (no code of this repo): large multi-block reductions inside a captured-and-replayed
 hipGraph return wrong values on this stack (ROCm 7.2 / PyTorch 2.10+rocm7.0, MI355X) after a few replays.
-This is why `use_hip_graph_update` (replaying whole PPO epochs, which are full of such reductions) is off by default;
-the rollout graph (`use_hip_graph`) contains no multi-block torch reduction and is verified bit-identical to eager
+This is why whole PPO epochs (full of such reductions) are NOT replayed as graphs -- the round-1 experiment
+`use_hip_graph_update` was removed in round 2 -- and why the rollout graph (`use_hip_graph`) accumulates its logged
+statistics element-wise per env and reduces them after the replay; it contains no torch reduction and is verified bit-identical to eager
 (tools/graph_rollout_soak.py).  Observations: every full-tensor reduction flavour (sum, mean, vector_norm, mean of squares) of
 >= 131 k elements fails, from the same replay index on (~815 with 24 reductions per replay) and then persistently; row-wise
 reductions ([600, 1024].sum(1)) and reductions of <= 32 k elements never do; a single such reduction per replay with changing

@@ -19,12 +19,8 @@ T = int(sys.argv[5]) if len(sys.argv) > 5 else 50
 cfg.update(n_rollout_threads=envs, n_eval_rollout_threads=0, save_model=False, n_iters=iters, ppo_epoch=2 if envs < 1000 else 1,
            max_ep_len=T, num_agents=A, num_pois=M)
 from learner import Learner
-if os.environ.get("SOAK_UPDATE_GRAPH", "0") == "1":     # experimental whole-epoch replay vs eager epochs (same capturable Adam)
-    cfg.update(ppo_epoch=15, use_hip_graph_update=True)
-    g = Learner(Namespace(**cfg)); e = Learner(Namespace(**cfg)); e.trainer.graph_update = False
-else:
-    g = Learner(Namespace(**dict(cfg, use_hip_graph=True)))
-    e = Learner(Namespace(**dict(cfg, use_hip_graph=False)))
+g = Learner(Namespace(**dict(cfg, use_hip_graph=True)))
+e = Learner(Namespace(**dict(cfg, use_hip_graph=False)))
 bad = 0
 for it in range(1, iters + 1):
     out = []
