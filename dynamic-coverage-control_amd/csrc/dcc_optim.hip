@@ -55,19 +55,21 @@ __global__ __launch_bounds__(64) void norm_finish_k(const float* __restrict__ pa
     out[1] = c;
 }
 
+// omb1 / omb2 = 1 - beta1 / 1 - beta2 rounded from DOUBLE precision, as torch passes them (1.f - 0.999f is off by 1.3e-5 relative)
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float clip, float step_size, float bc2_sqrt,
-                                      float beta1, float beta2, float eps, float wd) {
+                                      float omb1, float beta2, float omb2, float eps, float wd) {
     g *= clip;
     if (wd != 0.f) g += wd * p;
-    m = m + (g - m) * (1.f - beta1);                // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * beta2 + (1.f - beta2) * g * g;          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    m = m + (g - m) * omb1;                         // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * beta2 + omb2 * g * g;                   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
     const float denom = sqrtf(v) / bc2_sqrt + eps;
     p = p - step_size * (m / denom);                // param.addcdiv_(exp_avg, denom, value = -step_size)
 }
 
 __global__ __launch_bounds__(kBlock) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                  float* __restrict__ v, long long n, float step_size, float bc2_sqrt,
-                                                 float beta1, float beta2, float eps, float wd, const float* __restrict__ clip_p) {
+                                                 float omb1, float beta2, float omb2, float eps, float wd,
+                                                 const float* __restrict__ clip_p) {
     const float clip = clip_p ? *clip_p : 1.f;
     const long long n4 = n >> 2;
     float4* p4 = reinterpret_cast<float4*>(p);
@@ -77,15 +79,15 @@ __global__ __launch_bounds__(kBlock) void adam_k(float* __restrict__ p, const fl
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long long)gridDim.x * kBlock) {
         float4 pp = p4[i], mm = m4[i], vv = v4[i];
         const float4 gg = g4[i];
-        adam1(pp.x, gg.x, mm.x, vv.x, clip, step_size, bc2_sqrt, beta1, beta2, eps, wd);
-        adam1(pp.y, gg.y, mm.y, vv.y, clip, step_size, bc2_sqrt, beta1, beta2, eps, wd);
-        adam1(pp.z, gg.z, mm.z, vv.z, clip, step_size, bc2_sqrt, beta1, beta2, eps, wd);
-        adam1(pp.w, gg.w, mm.w, vv.w, clip, step_size, bc2_sqrt, beta1, beta2, eps, wd);
+        adam1(pp.x, gg.x, mm.x, vv.x, clip, step_size, bc2_sqrt, omb1, beta2, omb2, eps, wd);
+        adam1(pp.y, gg.y, mm.y, vv.y, clip, step_size, bc2_sqrt, omb1, beta2, omb2, eps, wd);
+        adam1(pp.z, gg.z, mm.z, vv.z, clip, step_size, bc2_sqrt, omb1, beta2, omb2, eps, wd);
+        adam1(pp.w, gg.w, mm.w, vv.w, clip, step_size, bc2_sqrt, omb1, beta2, omb2, eps, wd);
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long long i = (n4 << 2) + threadIdx.x;
-        adam1(p[i], g[i], m[i], v[i], clip, step_size, bc2_sqrt, beta1, beta2, eps, wd);
+        adam1(p[i], g[i], m[i], v[i], clip, step_size, bc2_sqrt, omb1, beta2, omb2, eps, wd);
     }
 }
 
@@ -115,14 +117,14 @@ DCC_API int dcc_grad_norm_clip(const float* grad, int64_t n, float max_norm, flo
 }
 
 DCC_API int dcc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float step_size,
-                          float bc2_sqrt, float beta1, float beta2, float eps, float weight_decay, const float* clip,
+                          float bc2_sqrt, double beta1, double beta2, float eps, float weight_decay, const float* clip,
                           void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1) return dcc_fail(kEINVAL, "dcc_adam_step: null pointer or n < 1");
     if (!(aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq)))
         return dcc_fail(kEINVAL, "dcc_adam_step: arrays must be 16-byte aligned");
     if (!(bc2_sqrt > 0.f)) return dcc_fail(kEINVAL, "dcc_adam_step: bc2_sqrt must be > 0 (step >= 1)");
     hipLaunchKernelGGL(adam_k, dim3(blocks_for(n)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), param, grad, exp_avg,
-                       exp_avg_sq, (long long)n, step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, clip);
+                       exp_avg_sq, (long long)n, step_size, bc2_sqrt, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, clip);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : dcc_fail(kEHIP, std::string("dcc_adam_step: ") + hipGetErrorString(e));
 }

@@ -95,7 +95,7 @@ def load_library(path=None):
     L.dcc_grad_norm_workspace_floats.argtypes = [i64]
     L.dcc_grad_norm_workspace_floats.restype = i64
     L.dcc_grad_norm_clip.argtypes = [_vp, i64, f32, _vp, _vp, _vp]
-    L.dcc_adam_step.argtypes = [_vp, _vp, _vp, _vp, i64, f32, f32, f32, f32, f32, f32, _vp, _vp]
+    L.dcc_adam_step.argtypes = [_vp, _vp, _vp, _vp, i64, f32, f32, ctypes.c_double, ctypes.c_double, f32, f32, _vp, _vp]
     if L.dcc_abi_version() != 2:
         raise DccError("libdcc_hip.so ABI version %d != 2" % L.dcc_abi_version())
     _lib = L

@@ -45,9 +45,9 @@ DCC_API int64_t dcc_grad_norm_workspace_floats(int64_t n);
 DCC_API int dcc_grad_norm_clip(const float* grad, int64_t n, float max_norm, float* out, float* workspace, void* stream);
 
 /* One Adam step on n elements in place (param, exp_avg, exp_avg_sq); clip: device pointer to the scale applied to the
- * gradient (NULL = 1). */
+ * gradient (NULL = 1).  beta1 / beta2 are doubles: 1 - beta is formed in double precision like torch forms it. */
 DCC_API int dcc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float step_size,
-                          float bc2_sqrt, float beta1, float beta2, float eps, float weight_decay, const float* clip,
+                          float bc2_sqrt, double beta1, double beta2, float eps, float weight_decay, const float* clip,
                           void* stream);
 
 #ifdef __cplusplus

@@ -67,9 +67,6 @@ def test_learner_runs_and_improves_nothing_breaks(tmp_path):
                main_save_path=str(tmp_path))
     lr = Learner(cfg)
     lr.train()
-    info = lr.trainer.train(lr.rl_buffer)
-    for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"):
-        assert np.isfinite(info[k]), k
     assert os.path.exists(os.path.join(lr.output_path, "models_2.pt", "agent.pkl"))
     # rollout invariants on the device buffer
     b = lr.rl_buffer
@@ -78,12 +75,24 @@ def test_learner_runs_and_improves_nothing_breaks(tmp_path):
     assert bool(((b.masks == 0) | (b.masks == 1)).all())
     # values identical across the agents of an env (centralised critic evaluated once per env)
     assert float((b.value_preds - b.value_preds[:, :, :1]).abs().max()) == 0.0
-    # checkpoint round trip
-    w0 = lr.policy.actor.state_dict()["act.action_out.fc_mean.weight"].clone()
-    lr.policy.actor.state_dict()["act.action_out.fc_mean.weight"].zero_()
-    lr.load_model(os.path.join(lr.output_path, "models_2.pt"))
-    lr2_w = lr.policy.actor.state_dict()["act.action_out.fc_mean.weight"]
-    assert lr2_w.abs().sum() > 0
+    # cfg.load_model / cfg.load_model_path (expt.yaml keys, like the reference): a fresh Learner CONTINUES the run from the
+    # directory save_model wrote -- iteration counter, parameters, optimizer moments, ValueNorm
+    lr2 = Learner(_cfg(**dict(vars(cfg), save_model=False, load_model=True, seed=123,
+                              load_model_path=os.path.join(lr.output_path, "models_2.pt"))))
+    assert lr2.start_iter == 3 and lr2.total_env_steps == lr.total_env_steps
+    for (k, a), (_, b2) in zip(lr.policy.actor.state_dict().items(), lr2.policy.actor.state_dict().items()):
+        assert torch.equal(a, b2), k
+    assert torch.equal(lr.policy.critic_optimizer.exp_avg_sq, lr2.policy.critic_optimizer.exp_avg_sq)
+    assert lr2.policy.actor_optimizer.step_count == lr.policy.actor_optimizer.step_count == 2 * 3
+    # agent.pkl alone (what the reference writes): parameters only
+    os.remove(os.path.join(lr.output_path, "models_2.pt", "resume.pt"))
+    lr2.policy.actor.state_dict()["act.action_out.fc_mean.weight"].zero_()
+    lr2.load_model(os.path.join(lr.output_path, "models_2.pt"))
+    assert torch.equal(lr2.policy.actor.state_dict()["act.action_out.fc_mean.weight"],
+                       lr.policy.actor.state_dict()["act.action_out.fc_mean.weight"])
+    info = lr.trainer.train(lr.rl_buffer)          # the buffer of the finished run is still trainable
+    for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"):
+        assert np.isfinite(info[k]), k
     ptu.set_gpu_mode(False)
 
 
@@ -371,12 +380,12 @@ def test_flat_adam_matches_torch_adam_and_clip_grad_norm():
             norms.append(float(n))
             np.testing.assert_allclose(float(n), float(rn), rtol=2e-6)
             for p, q in zip(ps, qs):
-                np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=2e-8)
+                np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=1e-5, atol=1e-7)
         for i, (p, off) in enumerate(zip(ps, flat._offsets)):
             st = ref.state[qs[i]]
-            np.testing.assert_allclose(flat.exp_avg[off:off + p.numel()].cpu().numpy(), st["exp_avg"].reshape(-1).cpu().numpy(), rtol=2e-6, atol=1e-9)
-            np.testing.assert_allclose(flat.exp_avg_sq[off:off + p.numel()].cpu().numpy(), st["exp_avg_sq"].reshape(-1).cpu().numpy(), rtol=2e-6, atol=1e-12)
-        assert all(p.data_ptr() % 256 == 0 for p in ps) and float(flat.flat_param[shapes[0][0] * shapes[0][1]:64 * 38].abs().sum()) == 0.0
+            np.testing.assert_allclose(flat.exp_avg[off:off + p.numel()].cpu().numpy(), st["exp_avg"].reshape(-1).cpu().numpy(), rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(flat.exp_avg_sq[off:off + p.numel()].cpu().numpy(), st["exp_avg_sq"].reshape(-1).cpu().numpy(), rtol=1e-5, atol=1e-10)
+        assert all(p.data_ptr() % 256 == 0 for p in ps) and float(flat.flat_param[flat._offsets[2] + 15:flat._offsets[3]].abs().sum()) == 0.0
         return norms, flat.flat_param.clone()
 
     for max_norm, wd, gscale in ((10.0, 0.0, 1.0), (10.0, 0.0, 0.01), (None, 0.0, 1.0), (0.5, 0.01, 3.0)):

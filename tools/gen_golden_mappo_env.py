@@ -1,7 +1,8 @@
 """Generate tests/golden/mappo_env_small.npz: the REFERENCE MAPPO update (algos.mappo / buffer.shared_buffer / utils.valuenorm
 imported from /root/reference/uav_dcc_control) on a rollout of the REFERENCE env (tools/ref_harness.py), i.e. with real
 observation rows -- the fixture the structured-input path (first layers from env-state features) is checked against directly.
-Container-only; the outputs are data.  Re-run: python tools/gen_golden_mappo_env.py
+Container-only; the outputs are data.  Re-run: python tools/gen_golden_mappo_env.py [small|n8m64]
+Second case `n8m64` (tests/golden/mappo_env_n8m64.npz): the BASELINE c2/c3 shape, 8 UAV x 64 PoI, E=2, T=31, hidden 32.
 
 4 UAV x 20 PoI (shipped world constants), E=3 envs, T=34 steps (env 1 flies east and finishes at step 30: one episode end + auto-reset), hidden 32, ppo_epoch 2.  Contents:
   poi [M,2]; state_pos/state_vel [T+1,E,N,2] f64, state_energy [T+1,E,M] f32, state_done [T+1,E,M] u8: the env state each
@@ -23,7 +24,7 @@ sys.path.insert(0, HERE)
 from ref_harness import make_reference_env  # noqa: E402  (installs the gym stub, puts the reference on sys.path)
 
 REF = "/root/reference/uav_dcc_control"
-OUT = os.path.join(HERE, "..", "tests", "golden", "mappo_env_small.npz")
+CASES = {"small": (4, 20, 3, 34, 32), "n8m64": (8, 64, 2, 31, 32)}     # N, M, E, T, H
 
 
 class Box:
@@ -39,7 +40,8 @@ def state_of(world):
     return pos, vel, en, dn
 
 
-def main():
+def main(case="small"):
+    OUT = os.path.join(HERE, "..", "tests", "golden", "mappo_env_%s.npz" % case)
     if REF not in sys.path:
         sys.path.insert(0, REF)
     import utils.pytorch_utils as ptu
@@ -47,7 +49,8 @@ def main():
     from algos.mappo import MAPPOPolicy, MAPPOTrainer
     from buffer.shared_buffer import SharedReplayBuffer
 
-    N, M, E, T, A, H = 4, 20, 3, 34, 2, 32
+    N, M, E, T, H = CASES[case]
+    A = 2
     D = 4 + 2 * (N - 1) + 5 * M
     S = N * D
     cfg = {}
@@ -138,4 +141,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else "small")
