@@ -664,6 +664,219 @@ __global__ __launch_bounds__(kBlock) void actor_l1_fwd_k(const float* __restrict
     }
 }
 
+// ---- actor first block, BASELINE sizes: NR agents per env fixed at compile time (4 / 8 UAVs, H <= 256, float4 lanes) ----
+// Two things bound the generic kernels above at 4.9 M rows: (1) Wh^T in LDS costs HD ds_read_b128 per lane and row (18 KB of
+// LDS reads per row at 8 UAVs: ~1.2 ms of pure LDS bandwidth per pass), (2) a row's inputs (72 B of head values, its moments)
+// are fetched one row ahead, which covers a fraction of the HBM latency at 4 waves per SIMD.  Here Wh^T lives in REGISTERS
+// (HD x 4 columns per lane), and everything an env's NR rows need -- the NR*HD head values as 1-3 coalesced loads, the NR
+// (mean, m2) pairs as one double2 load in lanes < NR, the G row -- is fetched a whole ENV ahead and broadcast per row with
+// compile-time readlanes.
+#ifndef DCC_L1F_WAVES
+#define DCC_L1F_WAVES 3     // waves per SIMD the env kernels are compiled for (register budget 512 / waves): at 4 the
+#endif                      // forward spills its prefetch registers to scratch, which serialises the HBM latency again
+#ifndef DCC_L1B_WAVES
+#define DCC_L1B_WAVES 2
+#endif
+template <int NR>
+struct EnvIn {
+    static constexpr int HD = 4 + 2 * (NR - 1);
+    static constexpr int HW = (NR * HD + 63) / 64;
+    float h[HW];
+    double2 st;
+    float G[4];
+};
+
+template <int NR>
+__device__ __forceinline__ void fetch_env(const float* __restrict__ head, const double* __restrict__ stats,
+                                          const float* __restrict__ G, long long e, int lane, EnvIn<NR>& in) {
+    constexpr int HD = EnvIn<NR>::HD;
+#pragma unroll
+    for (int w = 0; w < EnvIn<NR>::HW; ++w) {
+        const int idx = w * 64 + lane;
+        in.h[w] = idx < NR * HD ? head[e * (NR * HD) + idx] : 0.f;
+    }
+    in.st = make_double2(0.0, 0.0);
+    if (stats && lane < NR) in.st = reinterpret_cast<const double2*>(stats)[e * NR + lane];
+    ld<4>(G + e * 256 + lane * 4, in.G);
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+// 1 / sqrt(x) as ONE v_rsq_f32 (1 ulp; x = variance + eps is O(1e-5 .. 1e3) here, far from the denormal range).  The
+// IEEE-exact `1.0f / sqrtf(x)` of the generic kernels is ~30 instructions under -fno-fast-math, twice per row.  Forward and
+// backward of the env kernels use the same function, so the backward's recomputed activations are the forward's.
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// ReLU + LayerNorm moments of one full row of 256 (float4 per lane, every lane valid)
+__device__ __forceinline__ void row_stats_full(const float (&a)[4], float eps, float& mean, float& rstd) {
+    mean = wave_sum((a[0] + a[1]) + (a[2] + a[3])) * (1.0f / 256.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float d = a[j] - mean; q += d * d; }
+    rstd = fast_rsqrt(wave_sum(q) * (1.0f / 256.0f) + eps);
+}
+
+// Row i (runtime) of the env held in `in`: its HD head values gathered into ONE register (lane k <- head[i][k]) with one
+// ds_bpermute per held register, its input moments by readlane; then z = rstd_in * (head_i . Wh^T + G - mean_in s) + c with
+// the k-loop fully unrolled on compile-time readlanes.  The row loop itself stays rolled: unrolling it lets the scheduler
+// overlap rows and blows the register budget (measured: 256 VGPRs / 189 spills for the backward at 8 UAVs).
+template <int NR>
+__device__ __forceinline__ void env_row_z(const EnvIn<NR>& in, const int i, const int lane, const float (&w)[EnvIn<NR>::HD][4],
+                                          const bool has_stats, float invD, float eps_in, const float (&sv)[4],
+                                          const float (&cv)[4], float (&zr)[4], float& mean_in, float& rstd_in) {
+    constexpr int HD = EnvIn<NR>::HD;
+    const int f = i * HD + lane;
+    float hv = __shfl(in.h[0], f & 63, 64);
+#pragma unroll
+    for (int r = 1; r < EnvIn<NR>::HW; ++r) {
+        const float t = __shfl(in.h[r], f & 63, 64);
+        hv = (f >> 6) == r ? t : hv;
+    }
+    float u[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < HD; ++k) {
+        const float x = readlane_f(hv, k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] += x * w[k][j];
+    }
+    mean_in = 0.f; rstd_in = 1.f;
+    if (has_stats) {
+        mean_in = (float)readlane_d(in.st.x, i);
+        rstd_in = fast_rsqrt((float)readlane_d(in.st.y, i) * invD + eps_in);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zr[j] = rstd_in * (u[j] + in.G[j] - mean_in * sv[j]) + cv[j];
+}
+
+// H == 256 (every lane owns 4 valid columns: no predication anywhere in the row loop)
+template <int NR>
+__global__ __launch_bounds__(kBlock, DCC_L1F_WAVES) void actor_l1_fwd_env_k(const float* __restrict__ head, const float* __restrict__ G,
+                                                                const double* __restrict__ stats, const float* __restrict__ Wh,
+                                                                const float* __restrict__ s, const float* __restrict__ c,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float eps_in, float eps_ln, int D, float* __restrict__ h,
+                                                                long long n) {
+    constexpr int HD = EnvIn<NR>::HD, H = 256;
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * kWavesPerBlock;
+    const int cb = lane * 4;
+    float g[4], b[4], sv[4], cv[4], w[HD][4];
+    ld<4>(gamma + cb, g); ld<4>(beta + cb, b); ld<4>(s + cb, sv); ld<4>(c + cb, cv);
+#pragma unroll
+    for (int k = 0; k < HD; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[k][j] = Wh[(cb + j) * HD + k];
+    const float invD = 1.0f / (float)D;
+    const bool has_stats = stats != nullptr;
+    EnvIn<NR> cur, nxt;
+    if (gw < n) fetch_env<NR>(head, stats, G, gw, lane, cur);
+    for (long long e = gw; e < n; e += nw) {
+        if (e + nw < n) fetch_env<NR>(head, stats, G, e + nw, lane, nxt);   // a whole env ahead
+        float* hrow = h + e * NR * H + cb;
+#pragma unroll 1
+        for (int i = 0; i < NR; ++i) {
+            float a[4], mi, ri;
+            env_row_z<NR>(cur, i, lane, w, has_stats, invD, eps_in, sv, cv, a, mi, ri);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = fmaxf(a[j], 0.f);
+            float mean, rstd;
+            row_stats_full(a, eps_ln, mean, rstd);
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (a[j] - mean) * rstd * g[j] + b[j];
+            st<4>(hrow + (long long)i * H, o);
+        }
+        cur = nxt;
+    }
+}
+
+// Backward, q-storing form (dWh = q^T head is the caller's GEMM): the dh rows are streamed three rows ahead.
+template <int NR>
+__global__ __launch_bounds__(kBlock, DCC_L1B_WAVES) void actor_l1_bwd_env_k(const float* __restrict__ head, const float* __restrict__ G,
+                                                                const double* __restrict__ stats, const float* __restrict__ Wh,
+                                                                const float* __restrict__ s, const float* __restrict__ c,
+                                                                const float* __restrict__ gamma, const float* __restrict__ dh,
+                                                                float eps_in, float eps_ln, int D, float* __restrict__ dG,
+                                                                float* __restrict__ dq, float* __restrict__ ws, long long n) {
+    constexpr int HD = EnvIn<NR>::HD, H = 256;
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * kWavesPerBlock;
+    const int cb = lane * 4;
+    float g[4], sv[4], cv[4], w[HD][4];
+    float acc_g[4] = {0, 0, 0, 0}, acc_b[4] = {0, 0, 0, 0}, acc_s[4] = {0, 0, 0, 0}, acc_c[4] = {0, 0, 0, 0};
+    ld<4>(gamma + cb, g); ld<4>(s + cb, sv); ld<4>(c + cb, cv);
+#pragma unroll
+    for (int k = 0; k < HD; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[k][j] = Wh[(cb + j) * HD + k];
+    const float invD = 1.0f / (float)D;
+    const bool has_stats = stats != nullptr;
+    // look-ahead cursor over this wave's dh rows: (pe, pi) is the next row to fetch
+    long long pe = gw;
+    int pi = 0;
+    auto fetch_dh = [&](float (&dd)[4]) {
+        if (pe < n) {
+            ld<4>(dh + (pe * NR + pi) * H + cb, dd);
+            if (++pi == NR) { pi = 0; pe += nw; }
+        }
+    };
+    float nd[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    fetch_dh(nd[0]); fetch_dh(nd[1]); fetch_dh(nd[2]);
+    EnvIn<NR> cur, nxt;
+    if (gw < n) fetch_env<NR>(head, stats, G, gw, lane, cur);
+    for (long long e = gw; e < n; e += nw) {
+        if (e + nw < n) fetch_env<NR>(head, stats, G, e + nw, lane, nxt);
+        float dGv[4] = {0.f, 0.f, 0.f, 0.f};
+        float* qrow = dq + e * NR * H + cb;
+#pragma unroll 1
+        for (int i = 0; i < NR; ++i) {
+            float d[4], zr[4], a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { d[j] = nd[0][j]; nd[0][j] = nd[1][j]; nd[1][j] = nd[2][j]; }
+            fetch_dh(nd[2]);                                   // row t+3
+            float mean_in, rstd_in;
+            env_row_z<NR>(cur, i, lane, w, has_stats, invD, eps_in, sv, cv, zr, mean_in, rstd_in);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = fmaxf(zr[j], 0.f);
+            float mean, rstd;
+            row_stats_full(a, eps_ln, mean, rstd);
+            // LayerNorm + ReLU backward of the row (row_bwd, all lanes valid): d <- dL/dz
+            float xh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xh[j] = (a[j] - mean) * rstd;
+                acc_g[j] += d[j] * xh[j];
+                acc_b[j] += d[j];
+                d[j] *= g[j];
+                s1 += d[j];
+                s2 += d[j] * xh[j];
+            }
+            const float m1 = wave_sum(s1) * (1.0f / 256.0f), m2 = wave_sum(s2) * (1.0f / 256.0f);
+            float q[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d[j] = (zr[j] > 0.f) ? rstd * (d[j] - m1 - xh[j] * m2) : 0.f;
+                q[j] = rstd_in * d[j];
+                dGv[j] += q[j];
+                acc_s[j] -= mean_in * q[j];
+                acc_c[j] += d[j];
+            }
+            st<4>(qrow + (long long)i * H, q);
+        }
+        st<4>(dG + e * H + cb, dGv);
+        cur = nxt;
+    }
+    float* wv = ws + gw * 4 * H;     // per-wave partials [ds | dc | dgamma | dbeta] (the HDP = 0 layout of l1_reduce_k)
+    st<4>(wv + cb, acc_s); st<4>(wv + H + cb, acc_c); st<4>(wv + 2 * H + cb, acc_g); st<4>(wv + 3 * H + cb, acc_b);
+}
+
 // per-wave partial vector of the L1 backward: [dWt (HDP*H) | ds (H) | dc (H) | dgamma (H) | dbeta (H)].
 // HDP = 0: no dWh accumulators (they are what limits the kernel to 2 waves/SIMD); q = rstd_in * dz is stored instead.
 template <int VEC, int VPL, int HDP>
@@ -863,6 +1076,16 @@ void launch_l1_bwd(const Shape& sh, int grid, size_t lds, hipStream_t st_, A... 
     else hipLaunchKernelGGL((actor_l1_bwd_k<1, 2, HDP>), dim3(grid), dim3(kBlock), lds, st_, a...);
 }
 
+// Waves walk envs with a grid stride, so the grid must not exceed what is co-resident (a partly filled second round of
+// workgroups would add its whole duration): blocks = min(wanted, occupancy x CUs), occupancy queried once per kernel.
+int resident_blocks(const void* fn) {
+    int per_cu = 0, dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    return per_cu * cus;
+}
+
 constexpr int kSegWaves = 64;   // waves per stage-1 segment of the partial-sum reduction
 // stage 1 in place; returns the number of segments (the "waves" stage 2 sees, at stride kSegWaves * stride)
 long long reduce_stage1(float* ws, long long nw, int P, int stride, hipStream_t st_) {
@@ -1017,6 +1240,20 @@ DCC_API int dcc_actor_l1_fwd(const float* head, const float* G, const double* st
     if (sh.vec == 4 && !(aligned16(G) && aligned16(h) && aligned16(gamma) && aligned16(beta) && aligned16(s) && aligned16(c)))
         return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
+    if (H == 256 && HD == 4 + 2 * (N - 1) && (N == 8 || N == 4) && aligned16(stats) && aligned16(head)) {
+        // BASELINE sizes: Wh^T in registers, inputs fetched an env ahead (actor_l1_fwd_env_k)
+        static int res8 = 0, res4 = 0;
+        if (N == 8) {
+            if (!res8) res8 = resident_blocks(reinterpret_cast<const void*>(&actor_l1_fwd_env_k<8>));
+            hipLaunchKernelGGL((actor_l1_fwd_env_k<8>), dim3((int)waves_for(n, res8)), dim3(kBlock), 0, st_, head, G, stats, Wh, s, c, gamma,
+                               beta, eps_in, eps_ln, (int)D, h, (long long)n);
+        } else {
+            if (!res4) res4 = resident_blocks(reinterpret_cast<const void*>(&actor_l1_fwd_env_k<4>));
+            hipLaunchKernelGGL((actor_l1_fwd_env_k<4>), dim3((int)waves_for(n, res4)), dim3(kBlock), 0, st_, head, G, stats, Wh, s, c, gamma,
+                               beta, eps_in, eps_ln, (int)D, h, (long long)n);
+        }
+        return launch_status(__func__);
+    }
     const int grid = (int)waves_for(n, kL1Blocks * 2);
     LAUNCH_SHAPE(actor_l1_fwd_k, grid, lds, head, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, (int)D, h,
                  (long long)n, (int)N, (int)HD, (int)H);
@@ -1045,7 +1282,22 @@ DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* st
     if (dq) {   // two-kernel variant: light registers -> full occupancy, so use the larger grid too
         if (sh.vec == 4 && !aligned16(dq)) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
         grid_used = (int)waves_for(n, kL1Blocks * 2);
-        launch_l1_bwd<0>(sh, grid_used, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H);
+        if (H == 256 && HD == 4 + 2 * (N - 1) && (N == 8 || N == 4) && aligned16(stats) && aligned16(head)) {
+            static int res8 = 0, res4 = 0;      // BASELINE sizes: actor_l1_bwd_env_k, grid = what is co-resident
+            if (N == 8) {
+                if (!res8) res8 = resident_blocks(reinterpret_cast<const void*>(&actor_l1_bwd_env_k<8>));
+                if (res8 < grid_used) grid_used = res8;
+                hipLaunchKernelGGL((actor_l1_bwd_env_k<8>), dim3(grid_used), dim3(kBlock), 0, st_, head, G, stats, Wh, s, c, gamma, dh,
+                                   eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n);
+            } else {
+                if (!res4) res4 = resident_blocks(reinterpret_cast<const void*>(&actor_l1_bwd_env_k<4>));
+                if (res4 < grid_used) grid_used = res4;
+                hipLaunchKernelGGL((actor_l1_bwd_env_k<4>), dim3(grid_used), dim3(kBlock), 0, st_, head, G, stats, Wh, s, c, gamma, dh,
+                                   eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n);
+            }
+        } else {
+            launch_l1_bwd<0>(sh, grid_used, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H);
+        }
     } else {
         switch (hdp) {
             case 8: launch_l1_bwd<8>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;

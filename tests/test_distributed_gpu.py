@@ -18,3 +18,21 @@ def test_two_rank_gpu_training_keeps_replicas_identical():
                        env=dict(os.environ, DCC_DIST_BACKEND="gloo"))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "DIST_GPU_OK" in r.stdout
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two GPUs (the gpurun box has one)")
+def test_two_gpus_over_rccl():
+    """Runs wherever >= 2 GPUs are visible: bench.py --gpus 2 launches itself, the ranks rendezvous over RCCL
+    (backend nccl), the env shards scale weakly and the bounded c3 leg all-reduces the flat gradients over xGMI."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DCC_BENCH_BACKEND",
+                                                             "DCC_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--launches-per-step", "4",
+                        "--c3-iters", "1", "--ppo-epoch", "2", "--envs", "1024"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2048 and "error" not in d["c3"], d["c3"]
+    assert d["c3"]["grad_allreduce"] == "rccl x2" and all(v == v for v in d["c3"]["train_info"].values())

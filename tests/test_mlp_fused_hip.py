@@ -222,7 +222,9 @@ def test_actor_l1_backward_one_and_two_kernel_variants_agree(n, N, H):
     b = dcc_hip.actor_l1_bwd(head, G, stats, Wh, s, c, gamma, dh, 1e-5, 1e-5, 338, two_kernel=True)
     for name, x, y in zip(("dG", "dWh", "ds", "dc", "dgamma", "dbeta"), a, b):
         _close(y, x, name, rtol=1e-4, atol=1e-5)
-    assert torch.equal(a[0], b[0])       # dG takes the same in-register path in both
+    # (dG: the one-kernel form reads Wh^T from LDS in a k-loop, the q form holds it in registers fully unrolled: same sums, last-ulp
+    # differences in the pre-activation; run-to-run each form is bit-reproducible)
+    _close(b[0], a[0], "dG", rtol=1e-5, atol=1e-5)
     b2 = dcc_hip.actor_l1_bwd(head, G, stats, Wh, s, c, gamma, dh, 1e-5, 1e-5, 338, two_kernel=True)
     assert all(torch.equal(x, y) for x, y in zip(b, b2))
 
