@@ -118,7 +118,9 @@ class _ActorL1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, head, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, D):
         import dcc_hip
-        head, G, Wh, s, c = head.contiguous(), G.contiguous(), Wh.contiguous(), s.contiguous(), c.contiguous()
+        G, s, c = G.contiguous(), s.contiguous(), c.contiguous()
+        if head is not None:
+            head, Wh = head.contiguous(), Wh.contiguous()
         ctx.save_for_backward(head, G, stats, Wh, s, c, gamma)
         ctx.consts = (eps_in, eps_ln, D)
         return dcc_hip.actor_l1_fwd(head, G, stats, Wh, s, c, gamma.contiguous(), beta.contiguous(), eps_in, eps_ln, D)
@@ -134,14 +136,20 @@ class _ActorL1(torch.autograd.Function):
 
 
 def actor_l1(head, G, stats, Wh, s, c, ln, eps_in, D):
-    """h1 [n*N, H] = LayerNorm_ln(ReLU(rstd_in * (head Wh^T + G[env] - mean_in s) + c)); stats None = no input LN."""
-    n, N, HD = head.shape
+    """h1 [n*N, H] = LayerNorm_ln(ReLU(rstd_in * (head Wh^T + G[env] - mean_in s) + c)); stats None = no input LN.
+    head = Wh = None: one row per env and no per-row term (the centralised critic's first block: G is its whole GEMM)."""
+    if head is None:
+        n, N, HD = G.shape[0], 1, 0
+    else:
+        n, N, HD = head.shape
     if _usable(G, G.shape[1], HD):
         return _ActorL1.apply(head, G, stats, Wh, s, c, ln.weight, ln.bias, float(eps_in or 0.0), ln.eps, int(D))
-    z = F.linear(head.reshape(n * N, HD), Wh).view(n, N, -1) + G.to(Wh.dtype).unsqueeze(1)
+    z = G.unsqueeze(1)
+    if head is not None:
+        z = F.linear(head.reshape(n * N, HD), Wh).view(n, N, -1) + G.to(Wh.dtype).unsqueeze(1)
     if stats is not None:
-        rstd = torch.rsqrt(stats[..., 1] / D + eps_in).to(Wh.dtype).unsqueeze(-1)
-        z = rstd * (z - stats[..., 0].to(Wh.dtype).unsqueeze(-1) * s) + c
+        rstd = torch.rsqrt(stats[..., 1] / D + eps_in).to(G.dtype).unsqueeze(-1)
+        z = rstd * (z - stats[..., 0].to(G.dtype).unsqueeze(-1) * s) + c
     else:
         z = z + c
     return ln(F.relu(z.reshape(n * N, -1)))   # (the block's own Linear bias is already folded into c)

@@ -193,12 +193,46 @@ def _rest(base, h, head=None):
     return h if head is None else head(h)
 
 
+def _pad8(k):
+    return (k + 7) // 8 * 8
+
+
+def env_gemm_inputs(feats, critic):
+    """Input matrix of the per-env GEMM of the structured first layer, one row per env state, with a trailing column of ones
+    so that the constant term rides in the same GEMM (no broadcast add over the [n, H] result and no column-sum in its
+    backward), zero-padded to a multiple of 8 columns (16-byte aligned rows):
+        actor   X = [energy | done | 1 | 0..]                      -> G  = X [w_ed | const | 0]^T    shared by the env's agents
+        critic  X = [head_0 .. head_{N-1} | energy | done | 1 | 0..] -> y = X [w_h | w_ed | const | 0]^T
+    Parameter-free: the rollout buffer builds it once per chunk next to the features (key "xa" / "xc"); built on the fly when
+    the caller passed raw features."""
+    key = "xc" if critic else "xa"
+    x = feats.get(key)
+    if x is None:
+        head_f, poi_feat = feats["head"], feats["poi_feat"]
+        n = poi_feat.shape[0]
+        cols = ([head_f.reshape(n, -1)] if critic else []) + [poi_feat, torch.ones(n, 1, dtype=poi_feat.dtype, device=poi_feat.device)]
+        k = sum(c.shape[1] for c in cols)
+        if _pad8(k) > k:
+            cols.append(torch.zeros(n, _pad8(k) - k, dtype=poi_feat.dtype, device=poi_feat.device))
+        x = torch.cat(cols, dim=1)
+    return x
+
+
+def _env_gemm_weight(parts, const):
+    """[w.. | const | 0-padding]  [H, pad8(K + 1)] matching env_gemm_inputs."""
+    cols = list(parts) + [const.unsqueeze(1)]
+    k = sum(c.shape[1] for c in cols)
+    if _pad8(k) > k:
+        cols.append(torch.zeros(const.shape[0], _pad8(k) - k, dtype=const.dtype, device=const.device))
+    return torch.cat(cols, dim=1)
+
+
 def actor_trunk(base, layout, feats, head=None):
     """MLPBase(obs rows) for the n*N agent rows described by feats -> [n*N, H] (or head(.) -> [n*N, A])."""
-    head_f, poi_feat, stats = feats["head"], feats["poi_feat"], feats["stats"]
+    head_f, stats = feats["head"], feats["stats"]
     n, N, HD = head_f.shape
     w_h, w_ed, const, s_w, c, eps = folded_weights(base, layout, 1)      # [H,HD], [H,2M], [H], [H], [H]
-    g = fused.linear_w(poi_feat, w_ed) + const                          # [n, H] shared by the agents of an env
+    g = fused.linear_w(env_gemm_inputs(feats, False), _env_gemm_weight([w_ed], const))   # [n, H] shared by the agents of an env
     blk = base.mlp.fc1
     if isinstance(blk[1], nn.ReLU):   # one fused pass: the pre-activation never reaches memory (include/dcc_mlp.h)
         h = fused.actor_l1(head_f, g, stats if eps is not None else None, w_h, s_w, c, blk[2], eps, layout.D)
@@ -214,21 +248,29 @@ def actor_trunk(base, layout, feats, head=None):
 
 
 def critic_trunk(base, layout, feats, head=None):
-    """MLPBase(centralised rows = concat of the N agent rows of an env) -> [n, H] (or head(.) -> [n, A])."""
-    head_f, poi_feat, stats = feats["head"], feats["poi_feat"], feats["stats"]
+    """MLPBase(centralised rows = concat of the N agent rows of an env) -> [n, H] (or head(.) -> [n, A]).
+    ONE GEMM over [head_0..head_{N-1} | energy | done | 1] per env, then the same fused first-block tail as the actor's
+    (dcc_actor_l1 with one row per env and no per-row head term): input-LayerNorm correction, bias, ReLU, LayerNorm in one
+    pass, the pre-activation never stored."""
+    head_f, stats = feats["head"], feats["stats"]
     n, N, HD = head_f.shape
     w_h, w_ed, const, s_w, c, eps = folded_weights(base, layout, N)      # [H,N*HD], [H,2M], [H], [H], [H]
-    z = fused.linear_w(head_f.reshape(n, N * HD), w_h) + (fused.linear_w(poi_feat, w_ed) + const)
+    y = fused.linear_w(env_gemm_inputs(feats, True), _env_gemm_weight([w_h, w_ed], const))   # [n, H]
+    cstats = None
     if eps is not None:
         cstats = feats.get("cstats")
-        if cstats is not None:                                                 # pooled by dcc_obs_features
-            mean, m2 = cstats[:, 0:1], cstats[:, 1:2]
-        else:
+        if cstats is None:                                                     # pool the per-agent moments of the N*D-wide row
             mean_i, m2_i = stats[..., 0], stats[..., 1]                        # [n, N] float64
             mean = mean_i.mean(1, keepdim=True)
-            m2 = (m2_i + layout.D * (mean_i - mean) ** 2).sum(1, keepdim=True) # pooled moments of the N*D-wide row
-        rstd = torch.rsqrt(m2 / (N * layout.D) + eps)
-        z = rstd.to(z.dtype) * (z - mean.to(z.dtype) * s_w) + c
+            m2 = (m2_i + layout.D * (mean_i - mean) ** 2).sum(1, keepdim=True)
+            cstats = torch.cat([mean, m2], dim=1)
+    blk = base.mlp.fc1
+    if isinstance(blk[1], nn.ReLU):
+        h = fused.actor_l1(None, y, None if cstats is None else cstats.reshape(n, 1, 2), None, s_w, c, blk[2], eps, N * layout.D)
+        return _rest(base, h, head)
+    if cstats is not None:
+        rstd = torch.rsqrt(cstats[:, 1:2] / (N * layout.D) + eps)
+        z = rstd.to(y.dtype) * (y - cstats[:, 0:1].to(y.dtype) * s_w) + c
     else:
-        z = z + c
-    return _rest(base, _tail(base.mlp.fc1, z), head)
+        z = y + c
+    return _rest(base, _tail(blk, z), head)

@@ -125,8 +125,16 @@ class SharedReplayBuffer(object):
         return self.share_obs_env[t]
 
     def features_at(self, t):
-        """Compact policy-input features of slot t (structured mode): dict(head [E,N,HD], poi_feat [E,2M], stats)."""
-        return self._featurize(self.state_pos[t], self.state_vel[t], self.state_energy[t], self.state_done[t])
+        """Compact policy-input features of slot t (structured mode): dict(head [E,N,HD], poi_feat [E,2M], stats, cstats) plus
+        the per-env GEMM inputs xa / xc built from them (algo_utils/structured.py: env_gemm_inputs)."""
+        return self._with_gemm_inputs(self._featurize(self.state_pos[t], self.state_vel[t], self.state_energy[t], self.state_done[t]))
+
+    @staticmethod
+    def _with_gemm_inputs(f):
+        from algos.algo_utils.structured import env_gemm_inputs
+        f.pop("xa", None); f.pop("xc", None)
+        f["xa"], f["xc"] = env_gemm_inputs(f, False), env_gemm_inputs(f, True)
+        return f
 
     def features_rows(self, t0, t1):
         """Features of slots t0..t1-1 flattened over (step, env).  They do not depend on the parameters, so all PPO
@@ -139,7 +147,7 @@ class SharedReplayBuffer(object):
             n = (t1 - t0) * E
             f = self._featurize(self.state_pos[t0:t1].reshape(n, N, 2), self.state_vel[t0:t1].reshape(n, N, 2),
                                 self.state_energy[t0:t1].reshape(n, -1), self.state_done[t0:t1].reshape(n, -1), f)
-            self._feat_cache[key] = f
+            self._feat_cache[key] = self._with_gemm_inputs(f)
             self._feat_valid.add(key)
         return f
 

@@ -980,9 +980,11 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
                     acc_c[v][j] += d[v][j];
                 }
             if constexpr (HDP == 0) {   // two-kernel variant: q goes to memory, the caller forms dWh = q^T head as a GEMM
+                if (dq) {               // (HD = 0, the critic's first block: there is no head term and q = dG is all there is)
 #pragma unroll
-                for (int v = 0; v < VPL; ++v)
-                    if (ok[v]) st<VEC>(dq + r * H + cb[v], q[v]);
+                    for (int v = 0; v < VPL; ++v)
+                        if (ok[v]) st<VEC>(dq + r * H + cb[v], q[v]);
+                }
             }
 #pragma unroll
             for (int k = 0; k < HDP; ++k) {
@@ -1234,7 +1236,7 @@ DCC_API int dcc_actor_l1_fwd(const float* head, const float* G, const double* st
                              int32_t D, float* h, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
     if (!head || !G || !Wh || !s || !c || !gamma || !beta || !h || n < 1 || N < 1 || D < 1) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     Shape sh;
-    if (!pick_shape(H, sh) || HD < 1 || HD > 64 || pad_hd(HD) < 0) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (!pick_shape(H, sh) || HD < 0 || HD > 64 || pad_hd(HD) < 0) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
     const size_t lds = (size_t)HD * H * sizeof(float);
     if (lds > 64 * 1024) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
     if (sh.vec == 4 && !(aligned16(G) && aligned16(h) && aligned16(gamma) && aligned16(beta) && aligned16(s) && aligned16(c)))
@@ -1264,12 +1266,12 @@ DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* st
                              const float* c, const float* gamma, const float* dh, float eps_in, float eps_ln, int32_t D,
                              float* dG, float* dWh, float* dq, float* ds, float* dc, float* dgamma, float* dbeta,
                              float* workspace, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
-    if (!head || !G || !Wh || !s || !c || !gamma || !dh || !dG || (!dWh && !dq) || !ds || !dc || !dgamma || !dbeta ||
+    if (!head || !G || !Wh || !s || !c || !gamma || !dh || !dG || (HD > 0 && !dWh && !dq) || !ds || !dc || !dgamma || !dbeta ||
         !workspace || n < 1 || N < 1 || D < 1)
         return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     Shape sh;
     const int hdp = pad_hd(HD);
-    if (!pick_shape(H, sh) || HD < 1 || HD > 64 || hdp < 0) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (!pick_shape(H, sh) || HD < 0 || HD > 64 || hdp < 0) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
     const size_t lds = (size_t)HD * H * sizeof(float);
     if (lds > 64 * 1024) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
     if (sh.vec == 4 && !(aligned16(G) && aligned16(dh) && aligned16(dG) && aligned16(gamma) && aligned16(s) &&
@@ -1300,6 +1302,7 @@ DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* st
         }
     } else {
         switch (hdp) {
+            case 0: launch_l1_bwd<0>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
             case 8: launch_l1_bwd<8>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
             case 16: launch_l1_bwd<16>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
             case 24: launch_l1_bwd<24>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;

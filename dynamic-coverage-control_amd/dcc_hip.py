@@ -457,14 +457,19 @@ def rollout_record(reward, done, rewards_out, masks_out, n_agents):
 
 
 def actor_l1_fwd(head, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, D):
-    n, N, HD = head.shape
+    """head [n,N,HD] / Wh [H,HD], or both None: one row per env without a per-row head term (N = 1, HD = 0)."""
     H = G.shape[1]
-    h = torch.empty((n * N, H), dtype=torch.float32, device=head.device)
+    if head is None:
+        n, N, HD = G.shape[0], 1, 0
+        head = Wh = G          # never dereferenced with HD = 0: any valid pointer
+    else:
+        n, N, HD = head.shape
+    h = torch.empty((n * N, H), dtype=torch.float32, device=G.device)
     for t, nm in ((head, "head"), (G, "G"), (Wh, "Wh"), (s, "s"), (c, "c"), (gamma, "gamma"), (beta, "beta")):
         _f32c(t, nm)
     if stats is not None and (stats.dtype != torch.float64 or not stats.is_contiguous()):
         raise ValueError("stats must be contiguous float64")
-    with torch.cuda.device(head.device):
+    with torch.cuda.device(G.device):
         _check(load_library().dcc_actor_l1_fwd(_ptr(head), _ptr(G), _ptr(stats), _ptr(Wh), _ptr(s), _ptr(c), _ptr(gamma),
                                                _ptr(beta), eps_in, eps_ln, D, _ptr(h), n, N, HD, H, _stream()),
                "dcc_actor_l1_fwd")
@@ -473,19 +478,26 @@ def actor_l1_fwd(head, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, D):
 
 def actor_l1_bwd(head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, D, two_kernel=None):
     """-> dG, dWh, ds, dc, dgamma, dbeta.  two_kernel (default: for >= 65536 rows): the HIP kernel stores q = rstd_in * dz and
-    dWh = q^T head is issued as a split-K batched GEMM (see include/dcc_mlp.h)."""
-    n, N, HD = head.shape
+    dWh = q^T head is issued as a split-K batched GEMM (see include/dcc_mlp.h).  head = Wh = None (N = 1, HD = 0): dWh is
+    None and dG [n, H] is the gradient of the per-env GEMM output."""
     H = G.shape[1]
     L = load_library()
-    dev = head.device
+    dev = G.device
+    no_head = head is None
+    if no_head:
+        n, N, HD = G.shape[0], 1, 0
+        head = Wh = G
+        two_kernel = False
+    else:
+        n, N, HD = head.shape
     R = n * N
     if two_kernel is None:
         two_kernel = R >= 65536
     dG = torch.empty_like(G)
     vecs = torch.empty((4, H), dtype=torch.float32, device=dev)     # ds, dc, dgamma, dbeta
-    ws = torch.empty(L.dcc_mlp_workspace_floats(H, HD), dtype=torch.float32, device=dev)
+    ws = torch.empty(L.dcc_mlp_workspace_floats(H, max(HD, 1)), dtype=torch.float32, device=dev)
     dq = torch.empty((R, H), dtype=torch.float32, device=dev) if two_kernel else None
-    dWh = None if two_kernel else torch.empty((H, HD), dtype=torch.float32, device=dev)
+    dWh = None if (two_kernel or no_head) else torch.empty((H, HD), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _check(L.dcc_actor_l1_bwd(_ptr(head), _ptr(G), _ptr(stats), _ptr(Wh), _ptr(s), _ptr(c), _ptr(gamma),
                                   _ptr(_f32c(dh, "dh")), eps_in, eps_ln, D, _ptr(dG), _ptr(dWh), _ptr(dq), _ptr(vecs[0]),
