@@ -54,30 +54,37 @@ def _host_threads():
 
 
 def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, budget_s=10.0):
-    """Time the CPU restatement on a bounded sample of the same workload: every host thread steps
-    its own batch of 64 envs in chunks of 25 steps until `budget_s` seconds have passed."""
+    """Time the CPU restatement on a bounded sample of the same workload THROUGH THE SAME C-ABI as the GPU path: the
+    `_cpu` twins of include/dcc_env.h (oracle/dcc_env_cpu.c: dcc_env_rollout_cpu with the product's dcc_env_cfg /
+    dcc_env_out structs, host pointers).  Every host thread steps its own batch of 64 envs in fused rollouts of 25 steps
+    (in-kernel action stream, per-step reward / done / flags / coverage written, observation rows produced and cast to
+    float32 like the GPU writes them) until `budget_s` seconds have passed."""
     from oracle import oracle
     oracle.build()
     cores = _host_threads()
     E_thr, K = 64, 25
-    o = oracle.OracleEnv(E_thr, N, M, poi, r_cover, r_comm, crs, cfs)
-    o.reset()
+
+    def make():
+        e = oracle.CpuTwinEnv(E_thr, N, M, poi, r_cover, r_comm, crs, cfs)
+        e.reset()
+        return e, e.alloc_out(K, obs=True, assign=True)
+
+    o, out1 = make()
     t0 = time.perf_counter()
     n1 = 0
     while time.perf_counter() - t0 < 2.0:
-        o.rollout_rng(K, 0, step0=n1)
+        o.rollout(K, seed=0, step0=n1, out=out1)
         n1 += K
     rate1 = E_thr * n1 * N / (time.perf_counter() - t0)
     o.close()
-    envs = [oracle.OracleEnv(E_thr, N, M, poi, r_cover, r_comm, crs, cfs) for _ in range(cores)]
+    envs = [make() for _ in range(cores)]
     counts = [0] * cores
     deadline = [0.0]
 
     def work(i):
-        e = envs[i]
-        e.reset()
+        e, out = envs[i]
         while time.perf_counter() < deadline[0]:
-            e.rollout_rng(K, 1 + i, step0=counts[i])  # ctypes releases the GIL inside the C call
+            e.rollout(K, seed=1 + i, step0=counts[i], out=out)   # ctypes releases the GIL inside the C call
             counts[i] += K
 
     ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
@@ -94,10 +101,10 @@ def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, budget_s=10.0):
     except Exception:
         model = "unknown"
     return {"value": value, "unit": "agent-env-steps/s", "cores": cores, "kind": "port",
-            "sample": "oracle/dcc_oracle.c (C restatement of the reference env, float64): %d threads x %d envs, "
-                      "%.0f s of the c2 workload (N=%d, M=%d; %d env-steps in total) with the same counter-based "
-                      "random actions; single-thread rate %.0f agent-env-steps/s; host CPU: %s"
-                      % (cores, E_thr, dt, N, M, E_thr * sum(counts), rate1, model),
+            "sample": "oracle/dcc_env_cpu.c (the `_cpu` twins of include/dcc_env.h over the C restatement of the reference env, "
+                      "float64): dcc_env_rollout_cpu, %d threads x %d envs, %.0f s of the c2 workload (N=%d, M=%d; %d env-steps in "
+                      "total) with the same counter-based random actions, observation rows written; single-thread rate %.0f "
+                      "agent-env-steps/s; host CPU: %s" % (cores, E_thr, dt, N, M, E_thr * sum(counts), rate1, model),
             "value_1core": rate1}
 
 

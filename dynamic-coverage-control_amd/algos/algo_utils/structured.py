@@ -32,6 +32,10 @@ import torch.nn.functional as F
 from . import fused
 
 
+def _pad8(k):
+    return (k + 7) // 8 * 8
+
+
 class ObsLayout(object):
     """Column layout of an observation row (coverage.py:99-110) + the constants that appear in it."""
 
@@ -78,10 +82,12 @@ class _FoldedWeights(torch.autograd.Function):
         w_h [H, Nb*HD]  head columns of every block, the pos_i columns minus sum_j wf_xy,j
         w_ed [H, 2M]    energy and done columns, summed over the blocks
         const [H]       sum_j poi_j wf_xy,j + m_energy sum_j wf_m,j   (over all blocks)
+        w_env           the weight of the per-env GEMM (env_gemm_inputs): [w_ed | const | 0..] for the actor (Nb = 1, its head
+                        term is applied per agent row by the fused kernel), [w_h | w_ed | const | 0..] for the critic
     """
 
     @staticmethod
-    def forward(ctx, W, b, gamma, beta, poi, m_energy, Nb, HD, M):
+    def forward(ctx, W, b, gamma, beta, poi, m_energy, Nb, HD, M, with_head):
         H = W.shape[0]
         D = HD + 5 * M
         wf = W * gamma if gamma is not None else W
@@ -91,23 +97,32 @@ class _FoldedWeights(torch.autograd.Function):
         P = w3[:, :, HD:].reshape(H, Nb, M, 5)
         w_h = w3[:, :, :HD].clone()
         w_h[:, :, 2:4] -= P[..., 0:2].sum(2)
-        w_ed = torch.cat([P[..., 2].sum(1), P[..., 4].sum(1)], dim=1)
+        w_h = w_h.reshape(H, Nb * HD)
         const = (P[..., 0:2] * poi).sum((1, 2, 3)) + m_energy * P[..., 3].sum((1, 2))
+        k0 = Nb * HD if with_head else 0
+        w_env = W.new_zeros(H, _pad8(k0 + 2 * M + 1))
+        if k0:
+            w_env[:, :k0] = w_h
+        w_env[:, k0:k0 + M] = P[..., 2].sum(1)
+        w_env[:, k0 + M:k0 + 2 * M] = P[..., 4].sum(1)
+        w_env[:, k0 + 2 * M] = const
         ctx.save_for_backward(W, gamma, beta, poi)
-        ctx.dims = (Nb, HD, M, float(m_energy))
-        return w_h.reshape(H, Nb * HD), w_ed, const, s, c
+        ctx.dims = (Nb, HD, M, float(m_energy), bool(with_head))
+        return w_h, w_env, s, c
 
     @staticmethod
-    def backward(ctx, g_wh, g_wed, g_const, g_s, g_c):
+    def backward(ctx, g_wh, g_wenv, g_s, g_c):
         W, gamma, beta, poi = ctx.saved_tensors
-        Nb, HD, M, m_energy = ctx.dims
+        Nb, HD, M, m_energy, with_head = ctx.dims
         H = W.shape[0]
-        g_wh3 = g_wh.reshape(H, Nb, HD)
+        k0 = Nb * HD if with_head else 0
+        g_wh3 = (g_wh + g_wenv[:, :k0] if k0 else g_wh).reshape(H, Nb, HD)
+        g_const = g_wenv[:, k0 + 2 * M]
         gP = torch.empty(H, Nb, M, 5, dtype=W.dtype, device=W.device)
         gP[..., 0:2] = g_const.view(H, 1, 1, 1) * poi - g_wh3[:, :, 2:4].unsqueeze(2)
-        gP[..., 2] = g_wed[:, :M].unsqueeze(1)
+        gP[..., 2] = g_wenv[:, k0:k0 + M].unsqueeze(1)
         gP[..., 3] = (m_energy * g_const).view(H, 1, 1)
-        gP[..., 4] = g_wed[:, M:].unsqueeze(1)
+        gP[..., 4] = g_wenv[:, k0 + M:k0 + 2 * M].unsqueeze(1)
         g_wf = torch.cat([g_wh3, gP.view(H, Nb, 5 * M)], dim=2).view(H, -1) + g_s.unsqueeze(1)
         if gamma is not None:
             g_W = g_wf * gamma
@@ -118,11 +133,11 @@ class _FoldedWeights(torch.autograd.Function):
         if beta is not None:
             g_W = g_W + g_c.unsqueeze(1) * beta
             g_beta = g_c @ W
-        return g_W, g_c, g_gamma, g_beta, None, None, None, None, None
+        return g_W, g_c, g_gamma, g_beta, None, None, None, None, None, None
 
 
-def folded_weights(base, layout, Nb):
-    """(w_h, w_ed, const, s, c, eps) of the structured first layer of `base` (see _FoldedWeights).
+def folded_weights(base, layout, Nb, with_head=False):
+    """(w_h, w_env, s, c, eps) of the structured first layer of `base` (see _FoldedWeights).
 
     With autograd enabled this is a graph node.  Without (rollout / evaluation) the result only changes when the
     parameters do, so it is cached on `base` keyed by the parameters' version counters and refreshed IN PLACE -- the
@@ -134,12 +149,12 @@ def folded_weights(base, layout, Nb):
         gamma, beta, eps = ln.weight, ln.bias, ln.eps
     else:
         gamma = beta = eps = None
-    args = (lin.weight, lin.bias, gamma, beta, layout.poi(lin.weight), layout.m_energy, Nb, layout.HD, layout.M)
+    args = (lin.weight, lin.bias, gamma, beta, layout.poi(lin.weight), layout.m_energy, Nb, layout.HD, layout.M, with_head)
     if torch.is_grad_enabled() or torch.is_autocast_enabled():
         return _FoldedWeights.apply(*args) + (eps,)
     versions = tuple(-1 if t is None else t._version for t in (lin.weight, lin.bias, gamma, beta))
     cache = base.__dict__.setdefault("_folded_cache", {})
-    hit = cache.get(Nb)
+    hit = cache.get((Nb, with_head))
     if hit is None or hit[0] != versions or hit[1][0].device != lin.weight.device or hit[1][0].dtype != lin.weight.dtype:
         with torch.no_grad():
             fresh = _FoldedWeights.apply(*args)
@@ -150,7 +165,7 @@ def folded_weights(base, layout, Nb):
             hit = (versions, hit[1])
         else:
             hit = (versions, tuple(t.clone() for t in fresh))
-        cache[Nb] = hit
+        cache[(Nb, with_head)] = hit
     return hit[1] + (eps,)
 
 
@@ -171,7 +186,7 @@ def refresh_folded_weights(actor, critic):
         if getattr(actor, "obs_layout", None) is not None:
             folded_weights(actor.base, actor.obs_layout, 1)
         if getattr(critic, "obs_layout", None) is not None:
-            folded_weights(critic.base, critic.obs_layout, critic.obs_layout.N)
+            folded_weights(critic.base, critic.obs_layout, critic.obs_layout.N, True)
 
 
 def _tail(blk, z, bias=None):
@@ -191,10 +206,6 @@ def _rest(base, h, head=None):
             return fused.relu_ln_head(z, blk[0].bias, blk[2], head)
         h = _tail(blk, z, blk[0].bias)
     return h if head is None else head(h)
-
-
-def _pad8(k):
-    return (k + 7) // 8 * 8
 
 
 def env_gemm_inputs(feats, critic):
@@ -218,21 +229,12 @@ def env_gemm_inputs(feats, critic):
     return x
 
 
-def _env_gemm_weight(parts, const):
-    """[w.. | const | 0-padding]  [H, pad8(K + 1)] matching env_gemm_inputs."""
-    cols = list(parts) + [const.unsqueeze(1)]
-    k = sum(c.shape[1] for c in cols)
-    if _pad8(k) > k:
-        cols.append(torch.zeros(const.shape[0], _pad8(k) - k, dtype=const.dtype, device=const.device))
-    return torch.cat(cols, dim=1)
-
-
 def actor_trunk(base, layout, feats, head=None):
     """MLPBase(obs rows) for the n*N agent rows described by feats -> [n*N, H] (or head(.) -> [n*N, A])."""
     head_f, stats = feats["head"], feats["stats"]
     n, N, HD = head_f.shape
-    w_h, w_ed, const, s_w, c, eps = folded_weights(base, layout, 1)      # [H,HD], [H,2M], [H], [H], [H]
-    g = fused.linear_w(env_gemm_inputs(feats, False), _env_gemm_weight([w_ed], const))   # [n, H] shared by the agents of an env
+    w_h, w_env, s_w, c, eps = folded_weights(base, layout, 1)            # [H,HD], [H,pad8(2M+1)], [H], [H]
+    g = fused.linear_w(env_gemm_inputs(feats, False), w_env)             # [n, H] shared by the agents of an env
     blk = base.mlp.fc1
     if isinstance(blk[1], nn.ReLU):   # one fused pass: the pre-activation never reaches memory (include/dcc_mlp.h)
         h = fused.actor_l1(head_f, g, stats if eps is not None else None, w_h, s_w, c, blk[2], eps, layout.D)
@@ -254,8 +256,8 @@ def critic_trunk(base, layout, feats, head=None):
     pass, the pre-activation never stored."""
     head_f, stats = feats["head"], feats["stats"]
     n, N, HD = head_f.shape
-    w_h, w_ed, const, s_w, c, eps = folded_weights(base, layout, N)      # [H,N*HD], [H,2M], [H], [H], [H]
-    y = fused.linear_w(env_gemm_inputs(feats, True), _env_gemm_weight([w_h, w_ed], const))   # [n, H]
+    w_h, w_env, s_w, c, eps = folded_weights(base, layout, N, True)      # [H,N*HD], [H,pad8(N*HD+2M+1)], [H], [H]
+    y = fused.linear_w(env_gemm_inputs(feats, True), w_env)              # [n, H]
     cstats = None
     if eps is not None:
         cstats = feats.get("cstats")

@@ -131,9 +131,10 @@ class SharedReplayBuffer(object):
 
     @staticmethod
     def _with_gemm_inputs(f):
-        from algos.algo_utils.structured import env_gemm_inputs
-        f.pop("xa", None); f.pop("xc", None)
-        f["xa"], f["xc"] = env_gemm_inputs(f, False), env_gemm_inputs(f, True)
+        """dcc_obs_features_x writes xa / xc itself; a featurizer that does not (CPU tests) gets them derived here."""
+        if f.get("xa") is None or f.get("xc") is None:
+            from algos.algo_utils.structured import env_gemm_inputs
+            f["xa"], f["xc"] = env_gemm_inputs(f, False), env_gemm_inputs(f, True)
         return f
 
     def features_rows(self, t0, t1):

@@ -785,9 +785,15 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : 4)) void dcc_obs_expand_ker
 struct FeatParams {
     const double2* pos; const double2* vel; const float* energy; const uint8_t* done; const double2* poi;
     float* head; float* poi_feat; double* stats; double* cstats;
+    float* xa; float* xc;       // per-env GEMM inputs [energy | done | 1 | 0..] and [head_0..head_{N-1} | energy | done | 1 | 0..]
+    int ka, kc;                 // their row lengths (multiples of 8 floats)
     int n, N, M; float m_energy;
 };
 
+// PPL PoIs per lane, loaded ONCE into registers: the PoI coordinates / energies / done flags are re-used by every agent row
+// and both moment passes (read from global memory inside the agent loop they cost a dependent L2 round trip per agent and
+// pass: 16 at 8 UAVs, which made this kernel 30 us per 4096 states).
+template <int PPL>
 __global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatParams p) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -796,12 +802,23 @@ __global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatPara
     const int N = p.N, M = p.M, HD = 4 + 2 * (N - 1), D = HD + 5 * M;
     double2 mp = make_double2(0.0, 0.0), mv = mp;
     if (lane < N) { mp = p.pos[(size_t)n * N + lane]; mv = p.vel[(size_t)n * N + lane]; }
-    const float* en = p.energy + (size_t)n * M;
-    const uint8_t* dn = p.done + (size_t)n * M;
-    if (p.poi_feat) {
-        float* f = p.poi_feat + (size_t)n * 2 * M;
-        for (int j = lane; j < M; j += 64) { f[j] = en[j]; f[M + j] = dn[j] ? 1.f : 0.f; }
+    double qx[PPL], qy[PPL], enq[PPL], dnq[PPL];
+#pragma unroll
+    for (int t = 0; t < PPL; ++t) {
+        const int j = t * 64 + lane;
+        qx[t] = qy[t] = enq[t] = dnq[t] = 0.0;
+        if (j < M) {
+            const double2 q = p.poi[j];
+            const float e = p.energy[(size_t)n * M + j];
+            const float d = p.done[(size_t)n * M + j] ? 1.f : 0.f;
+            qx[t] = q.x; qy[t] = q.y; enq[t] = (double)e; dnq[t] = (double)d;
+            if (p.poi_feat) { float* f = p.poi_feat + (size_t)n * 2 * M; f[j] = e; f[M + j] = d; }
+            if (p.xa) { float* f = p.xa + (size_t)n * p.ka; f[j] = e; f[M + j] = d; }
+            if (p.xc) { float* f = p.xc + (size_t)n * p.kc + N * HD; f[j] = e; f[M + j] = d; }
+        }
     }
+    if (p.xa) { const int c = 2 * M + lane; if (c < p.ka) p.xa[(size_t)n * p.ka + c] = lane == 0 ? 1.f : 0.f; }          // 1 | zero padding (< 8)
+    if (p.xc) { const int c = N * HD + 2 * M + lane; if (c < p.kc) p.xc[(size_t)n * p.kc + c] = lane == 0 ? 1.f : 0.f; }
     const double me = (double)p.m_energy;
     double my_mean = 0.0, my_m2 = 0.0;     // lane i keeps the moments of agent row i (for the pooled critic moments)
     for (int i = 0; i < N; ++i) {
@@ -809,30 +826,38 @@ __global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatPara
         const float rx = (float)(mp.x - px), ry = (float)(mp.y - py);   // what the obs row holds for agent `lane`
         const bool other = lane < N && lane != i;
         const float v0 = (float)mv.x, v1 = (float)mv.y, p0 = (float)mp.x, p1 = (float)mp.y;
-        if (p.head) {
-            float* h = p.head + ((size_t)n * N + i) * HD;
-            if (lane == i) { h[0] = v0; h[1] = v1; h[2] = p0; h[3] = p1; }
-            if (other) { const int k = lane < i ? lane : lane - 1; h[4 + 2 * k] = rx; h[5 + 2 * k] = ry; }
+        if (p.head || p.xc) {
+            float* h = p.head ? p.head + ((size_t)n * N + i) * HD : nullptr;
+            float* x = p.xc ? p.xc + (size_t)n * p.kc + i * HD : nullptr;
+            if (lane == i) {
+                if (h) { h[0] = v0; h[1] = v1; h[2] = p0; h[3] = p1; }
+                if (x) { x[0] = v0; x[1] = v1; x[2] = p0; x[3] = p1; }
+            }
+            if (other) {
+                const int k = lane < i ? lane : lane - 1;
+                if (h) { h[4 + 2 * k] = rx; h[5 + 2 * k] = ry; }
+                if (x) { x[4 + 2 * k] = rx; x[5 + 2 * k] = ry; }
+            }
         }
         if (!p.stats && !p.cstats) continue;
         // two-pass moments of the D float32 values of the row, accumulated in float64
         double s = 0.0;
         if (lane == i) s = ((double)v0 + (double)v1) + ((double)p0 + (double)p1);
         if (other) s = (double)rx + (double)ry;
-        for (int j = lane; j < M; j += 64) {
-            const double2 q = p.poi[j];
-            s += (double)(float)(q.x - px) + (double)(float)(q.y - py) + (double)en[j] + me + (dn[j] ? 1.0 : 0.0);
+        float fx[PPL], fy[PPL];
+#pragma unroll
+        for (int t = 0; t < PPL; ++t) {
+            fx[t] = (float)(qx[t] - px); fy[t] = (float)(qy[t] - py);
+            if (t * 64 + lane < M) s += (double)fx[t] + (double)fy[t] + enq[t] + me + dnq[t];
         }
         const double mean = wave_sum_f64(s) / (double)D;
         double m2 = 0.0;
         auto sq = [mean](double x) { const double d = x - mean; return d * d; };
         if (lane == i) m2 = sq((double)v0) + sq((double)v1) + sq((double)p0) + sq((double)p1);
         if (other) m2 = sq((double)rx) + sq((double)ry);
-        for (int j = lane; j < M; j += 64) {
-            const double2 q = p.poi[j];
-            m2 += sq((double)(float)(q.x - px)) + sq((double)(float)(q.y - py)) + sq((double)en[j]) + sq(me) +
-                  sq(dn[j] ? 1.0 : 0.0);
-        }
+#pragma unroll
+        for (int t = 0; t < PPL; ++t)
+            if (t * 64 + lane < M) m2 += sq((double)fx[t]) + sq((double)fy[t]) + sq(enq[t]) + sq(me) + sq(dnq[t]);
         m2 = wave_sum_f64(m2);
         if (lane == 0 && p.stats) { p.stats[((size_t)n * N + i) * 2] = mean; p.stats[((size_t)n * N + i) * 2 + 1] = m2; }
         if (lane == i) { my_mean = mean; my_m2 = m2; }
@@ -1550,24 +1575,40 @@ int dcc_obs_expand(dcc_env* e, int64_t n, const double* pos, const double* vel, 
     return DCC_OK;
 }
 
-int dcc_obs_features(dcc_env* e, int64_t n, const double* pos, const double* vel, const float* energy,
-                     const uint8_t* done, float* head, float* poi_feat, double* stats, double* cstats, void* stream) {
+int dcc_obs_features_x(dcc_env* e, int64_t n, const double* pos, const double* vel, const float* energy,
+                       const uint8_t* done, float* head, float* poi_feat, double* stats, double* cstats, float* xa, float* xc,
+                       void* stream) {
     if (!e) return fail(DCC_EINVAL, "dcc_obs_features: null env");
     if (n < 1 || n > 0x7fffffffLL) return fail(DCC_EINVAL, "dcc_obs_features: n out of range");
     if (!pos || !vel || !energy || !done) return fail(DCC_EINVAL, "dcc_obs_features: null state pointer");
     if ((reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(vel)) & 15u)
         return fail(DCC_EINVAL, "dcc_obs_features: pos / vel must be 16-byte aligned");
-    if (!head && !poi_feat && !stats && !cstats) return DCC_OK;
+    if (!head && !poi_feat && !stats && !cstats && !xa && !xc) return DCC_OK;
     DeviceGuard guard(e->device);
     FeatParams p;
     p.pos = reinterpret_cast<const double2*>(pos); p.vel = reinterpret_cast<const double2*>(vel);
     p.energy = energy; p.done = done; p.poi = e->d_poi;
     p.head = head; p.poi_feat = poi_feat; p.stats = stats; p.cstats = cstats;
     p.n = (int)n; p.N = e->cfg.n_agents; p.M = e->cfg.n_pois; p.m_energy = (float)e->cfg.m_energy;
+    p.xa = xa; p.xc = xc;
+    p.ka = (2 * p.M + 1 + 7) / 8 * 8;
+    p.kc = (p.N * (4 + 2 * (p.N - 1)) + 2 * p.M + 1 + 7) / 8 * 8;
     const int grid = (int)((n + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(dcc_obs_features_kernel, dim3(grid), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (e->PPL) {
+        case 1: hipLaunchKernelGGL(dcc_obs_features_kernel<1>, dim3(grid), dim3(kBlock), 0, s, p); break;
+        case 2: hipLaunchKernelGGL(dcc_obs_features_kernel<2>, dim3(grid), dim3(kBlock), 0, s, p); break;
+        case 4: hipLaunchKernelGGL(dcc_obs_features_kernel<4>, dim3(grid), dim3(kBlock), 0, s, p); break;
+        case 8: hipLaunchKernelGGL(dcc_obs_features_kernel<8>, dim3(grid), dim3(kBlock), 0, s, p); break;
+        default: hipLaunchKernelGGL(dcc_obs_features_kernel<16>, dim3(grid), dim3(kBlock), 0, s, p); break;
+    }
     HIP_TRY(hipGetLastError());
     return DCC_OK;
+}
+
+int dcc_obs_features(dcc_env* e, int64_t n, const double* pos, const double* vel, const float* energy,
+                     const uint8_t* done, float* head, float* poi_feat, double* stats, double* cstats, void* stream) {
+    return dcc_obs_features_x(e, n, pos, vel, energy, done, head, poi_feat, stats, cstats, nullptr, nullptr, stream);
 }
 
 int dcc_env_get_state(dcc_env* e, double* pos, double* vel, float* energy, uint8_t* done, void* stream) {

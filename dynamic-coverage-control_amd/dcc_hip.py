@@ -42,7 +42,7 @@ class EnvOut(ctypes.Structure):
 
 EXPORTS = ["dcc_obs_expand", "dcc_gae_compute", "dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
            "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout", "dcc_env_get_state",
-           "dcc_env_set_state", "dcc_env_bytes_per_step", "dcc_obs_features",
+           "dcc_env_set_state", "dcc_env_bytes_per_step", "dcc_obs_features", "dcc_obs_features_x",
            "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_relu_ln_head_fwd", "dcc_relu_ln_head_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd", "dcc_ppo_policy_loss",
            "dcc_rollout_sample", "dcc_rollout_record", "dcc_ppo_value_loss",
            "dcc_grad_norm_workspace_floats", "dcc_grad_norm_clip", "dcc_adam_step"]
@@ -79,6 +79,7 @@ def load_library(path=None):
                                   ctypes.c_int64, _vp]
     L.dcc_obs_expand.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]
     L.dcc_obs_features.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.dcc_obs_features_x.argtypes = [_vp, ctypes.c_int64] + [_vp] * 11
     f32, i32, i64 = ctypes.c_float, ctypes.c_int32, ctypes.c_int64
     L.dcc_relu_ln_fwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, i64, i32, _vp]
     L.dcc_relu_ln_bwd.argtypes = [_vp, _vp, _vp, _vp, f32, _vp, _vp, _vp, i64, i32, _vp]
@@ -201,7 +202,8 @@ class HipCoverageEnv:
     def obs_features(self, pos, vel, energy, done, out=None):
         """Compact policy-input features of n states (include/dcc_env.h: dcc_obs_features):
         dict(head [n,N,4+2(N-1)] f32, poi_feat [n,2M] f32, stats [n,N,2] f64 = (mean, sum sq. dev.) of each obs row,
-        cstats [n,2] f64 = the same moments of the centralised row)."""
+        cstats [n,2] f64 = the same moments of the centralised row, xa / xc = the per-env GEMM inputs of
+        dcc_obs_features_x).  `out`: a dict naming the outputs wanted (missing keys are skipped)."""
         n = pos.shape[0]
         want = ((pos, (n, self.N, 2), torch.float64), (vel, (n, self.N, 2), torch.float64),
                 (energy, (n, self.M), torch.float32), (done, (n, self.M), torch.uint8))
@@ -209,8 +211,10 @@ class HipCoverageEnv:
             if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
                 raise ValueError("obs_features: need contiguous %s %s on %s" % (shape, dt, self.device))
         HD = 4 + 2 * (self.N - 1)
+        ka, kc = (2 * self.M + 1 + 7) // 8 * 8, (self.N * HD + 2 * self.M + 1 + 7) // 8 * 8
         shapes = dict(head=((n, self.N, HD), torch.float32), poi_feat=((n, 2 * self.M), torch.float32),
-                      stats=((n, self.N, 2), torch.float64), cstats=((n, 2), torch.float64))
+                      stats=((n, self.N, 2), torch.float64), cstats=((n, 2), torch.float64),
+                      xa=((n, ka), torch.float32), xc=((n, kc), torch.float32))
         if out is None:
             out = {k: torch.empty(sh, dtype=dt, device=self.device) for k, (sh, dt) in shapes.items()}
         for k, (sh, dt) in shapes.items():
@@ -218,9 +222,10 @@ class HipCoverageEnv:
             if t is not None and (tuple(t.shape) != sh or t.dtype != dt or not t.is_contiguous()):
                 raise ValueError("obs_features: output %r must be contiguous %s %s" % (k, sh, dt))
         with torch.cuda.device(self.device):
-            _check(self.lib.dcc_obs_features(self._h, n, _ptr(pos), _ptr(vel), _ptr(energy), _ptr(done),
-                                             _ptr(out.get("head")), _ptr(out.get("poi_feat")), _ptr(out.get("stats")),
-                                             _ptr(out.get("cstats")), _stream()), "dcc_obs_features")
+            _check(self.lib.dcc_obs_features_x(self._h, n, _ptr(pos), _ptr(vel), _ptr(energy), _ptr(done),
+                                               _ptr(out.get("head")), _ptr(out.get("poi_feat")), _ptr(out.get("stats")),
+                                               _ptr(out.get("cstats")), _ptr(out.get("xa")), _ptr(out.get("xc")), _stream()),
+                   "dcc_obs_features_x")
         return out
 
     def _out_struct(self, out, K=None):

@@ -151,6 +151,16 @@ DCC_API int dcc_obs_features(dcc_env* env, int64_t n, const double* pos, const d
                              const uint8_t* done, float* head, float* poi_feat, double* stats, double* cstats,
                              void* stream);
 
+/* dcc_obs_features plus the input matrices of the per-env GEMMs of the structured first layers (any output may be NULL),
+ * each row zero-padded to a multiple of 8 floats so that rows stay 16-byte aligned:
+ *   xa [n, pad8(2M + 1)]                 float32   [energy | done | 1 | 0..]                       (actor: the term its N agents share)
+ *   xc [n, pad8(N(4+2(N-1)) + 2M + 1)]   float32   [head_0 .. head_{N-1} | energy | done | 1 | 0..] (centralised critic)
+ * The trailing 1 lets the constant term of the layer ride in the GEMM.  Written by the same kernel that produces the
+ * features: no concatenation passes on the caller's side. */
+DCC_API int dcc_obs_features_x(dcc_env* env, int64_t n, const double* pos, const double* vel, const float* energy,
+                               const uint8_t* done, float* head, float* poi_feat, double* stats, double* cstats,
+                               float* xa, float* xc, void* stream);
+
 /* Algorithmic HBM bytes of one env-step (SURVEY.md section 8d, fp32 I/O contract):
  * 40N + 11M + 11 + 4*N*D; with_actions=0 drops 8N; with_obs=0 drops 4*N*D. */
 DCC_API int64_t dcc_env_bytes_per_step(int32_t n_agents, int32_t n_pois, int32_t with_actions, int32_t with_obs);
