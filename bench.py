@@ -344,16 +344,19 @@ def main():
         dt = float(tt.item())
 
     env_steps = args.steps * L * T          # batched env steps in the timed region
+    shape_name = {(8, 64, 4096): "c2 (BASELINE configs[1])", (16, 256, 1024): "c4 per-GPU shard (BASELINE configs[3]: 8192 envs over 8 GPUs)",
+                  (32, 1024, 2048): "c5 per-GPU shard (BASELINE configs[4]: 16384 envs over 8 GPUs%s)" % ("" if cfs > 0 else ", pull force OFF"),
+                  (4, 16, 4096): "c1 size (BASELINE configs[0] shape) batched"}.get((N, M, E), "custom shape")
     value = world * E * N * env_steps / dt
     res = {
         "metric": "agent_env_steps_per_sec", "value": value, "unit": "agent-env-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "c2 (BASELINE configs[1]): %d UAV x %d PoI x %d envs per GPU, random-action env-step HIP kernel "
+        "config": {"workload": "%s: %d UAV x %d PoI x %d envs per GPU, random-action env-step HIP kernel "
                                "only, weak scaling over GPUs (%d envs job-wide); one bench step = %d rollouts = %d fused launches "
                                "x %d batched env steps; actions %s, obs %s" % (
-                                   N, M, E, world * E, L, L, T,
+                                   shape_name, N, M, E, world * E, L, L, T,
                                    "read from HBM [T,E,N,2] f32" if actions is not None else "drawn in-kernel",
                                    "skipped" if args.no_obs else "written to HBM [T,E,N,D] f32"),
                    "n_agents": N, "n_pois": M, "envs_per_gpu": E, "global_envs": world * E,

@@ -229,8 +229,11 @@ class HipCoverageEnv:
         return out
 
     def _out_struct(self, out, K=None):
-        # the same output tensors are passed step after step: validate and build the C struct once
-        key = (K,) + tuple((k, t.data_ptr()) for k, t in out.items() if t is not None)
+        # the same output tensors are passed step after step: validate and build the C struct once.  The key carries
+        # everything the validation looks at (an address alone can be recycled by the caching allocator for a tensor of
+        # another shape / dtype, which would then inherit a stale validation and let the kernel write out of bounds)
+        key = (K,) + tuple((k, t.data_ptr(), tuple(t.shape), t.dtype, t.is_contiguous(), t.device.index)
+                           for k, t in out.items() if t is not None)
         if key == getattr(self, "_out_key", None):
             return self._out_cached
         o = self._build_out_struct(out, K)
