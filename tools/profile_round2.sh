@@ -52,11 +52,10 @@ python - <<'PY'
 import json, re
 out = 'gpurun_out/profiles_r02/'
 def per_launch(name):
-    for l in open(out + name):
-        if 'roles_kernel' in l or 'dcc_env_kernel' in l:
-            m = re.search(r'total=([0-9.e+]+)', l)
-            if m and 'n=' in l:
-                return float(m.group(1))
+    for l in open(out + name):         # tools/pmc_summary.py line of the 150-step launches: "... <COUNTER>  n=8  total=6.546e+06 ..."
+        m = re.search(r'total=([0-9.e+]+)', l)
+        if m and 'n=' in l:
+            return float(m.group(1))
     return None
 w, f = per_launch('pmc_WRITE_SIZE.txt'), per_launch('pmc_FETCH_SIZE.txt')
 cal = 1.0
