@@ -114,6 +114,9 @@ DCC_API int dcc_rollout_record(const float* reward, const uint8_t* done, float* 
  *   Wh [H,HD], s [H] (row sums of the folded weight), c [H] (folded bias);  D = observation width, eps_in = input-LN eps
  *   gamma, beta [H], eps_ln                  the block's LayerNorm
  *   h     [n*N,H]  f32 out
+ * HD = 0 (N = 1; head / Wh are then never dereferenced, pass any valid pointer): no per-row term -- z = rstd_in * (G - mean_in
+ * s) + c with one row per env: the first-block tail of the centralised critic, whose whole per-env GEMM output is G.
+ * 4 or 8 UAVs with H = 256 (the BASELINE sizes) take kernels that hold Wh^T in registers and fetch an env ahead.
  */
 DCC_API int dcc_actor_l1_fwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
                              const float* c, const float* gamma, const float* beta, float eps_in, float eps_ln,
@@ -123,7 +126,8 @@ DCC_API int dcc_actor_l1_fwd(const float* head, const float* G, const double* st
  * dq == NULL: one kernel, dWh accumulated in registers (~100 per lane -> 2 waves/SIMD).
  * dq != NULL ([n*N,H]): the kernel stores q = rstd_in * dL/dz there instead and leaves dWh untouched -- the caller
  * forms dWh = q^T head as a (split-K) GEMM; without the accumulators the kernel runs at full occupancy, which is
- * faster for long batches even with the extra [rows,H] write (4.2 vs 7.1 ms at 4.9 M rows). */
+ * faster for long batches even with the extra [rows,H] write (2.7 vs 7.1 ms at 4.9 M rows).  HD = 0: dWh and dq may both be
+ * NULL (dG is then the gradient of the per-env GEMM output). */
 DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
                              const float* c, const float* gamma, const float* dh, float eps_in, float eps_ln, int32_t D,
                              float* dG, float* dWh, float* dq, float* ds, float* dc, float* dgamma, float* dbeta,

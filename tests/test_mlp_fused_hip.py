@@ -314,3 +314,46 @@ def test_fused_value_loss_matches_autograd(n, N, huber, clipped, masked, normed)
     _close(f[1], t[1], "dvalues", rtol=2e-5, atol=2e-6)
     f2 = run(True)
     assert torch.equal(f[0], f2[0]) and torch.equal(f[1], f2[1])
+
+
+@pytest.mark.parametrize("n,H,with_stats", [(517, 256, True), (64, 64, True), (9000, 256, False), (3, 32, True)])
+def test_critic_first_block_tail_no_head_term(n, H, with_stats):
+    """dcc_actor_l1 with one row per env and NO per-row head term (N = 1, HD = 0): the centralised critic's first block after
+    its per-env GEMM,  h = LayerNorm(ReLU(rstd_in (y - mean_in s) + c)).  Values, dy (= dG), ds, dc, dgamma, dbeta against the
+    torch formulation; bit-reproducible."""
+    from algos.algo_utils import fused
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(n + H)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    ln = torch.nn.LayerNorm(H).to(dev)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-0.3, 0.3)
+    stats = None
+    if with_stats:
+        stats = torch.stack([rnd(n, 1).double() * 0.1 + 1.0, torch.rand(n, 1, device=dev, generator=g).double() * 300 + 600], -1).contiguous()
+    D = 10816
+    dh = rnd(n, H)
+
+    def run(enabled):
+        fused.ENABLED = enabled
+        try:
+            ln.zero_grad()
+            y = (rnd(n, H) * 0 + y0).requires_grad_(True)
+            s = s0.clone().requires_grad_(True); c = c0.clone().requires_grad_(True)
+            h = fused.actor_l1(None, y, stats, None, s, c, ln, 1e-5, D)
+            if enabled:
+                assert "ActorL1" in type(h.grad_fn).__name__        # the HIP path ran
+            h.backward(dh)
+            gs = s.grad if s.grad is not None else torch.zeros_like(s)       # no input LayerNorm: s does not enter
+            return h.detach().clone(), [y.grad.clone(), gs.clone(), c.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone()]
+        finally:
+            fused.ENABLED = True
+
+    y0, s0, c0 = rnd(n, H) * 1.5, rnd(H), rnd(H)
+    h_f, g_f = run(True)
+    h_t, g_t = run(False)
+    _close(h_f, h_t, "h", rtol=1e-4, atol=1e-5)
+    for name, a, b in zip(("dy", "ds", "dc", "dgamma", "dbeta"), g_f, g_t):
+        _close_grad(a, b, name, n * H)
+    h_f2, g_f2 = run(True)
+    assert torch.equal(h_f, h_f2) and all(torch.equal(a, b) for a, b in zip(g_f, g_f2))
