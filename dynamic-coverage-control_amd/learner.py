@@ -201,7 +201,9 @@ class Learner:
                 try:
                     torch.cuda.synchronize()
                     graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
+                    # thread_local: activity of OTHER threads (the RCCL watchdog polling its events in a multi-GPU job) must
+                    # not invalidate the capture; the captured body itself issues no collective
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                         gstats = self._rollout_body(r_buffer, r_envs)
                     self._graphs[key] = (graph, gstats)
                 except Exception as e:  # capture is an optimisation only: keep running eagerly
