@@ -15,7 +15,8 @@ byte contract of SURVEY.md section 8d (11,851 B per env-step at c2).  One step i
 
 Prints ONE JSON line on rank 0.  `roofline` is always measured live: HIP events around every timed
 launch on the launch stream.  `cpu_baseline` times the CPU oracle (oracle/dcc_oracle.c, "port") on
-the host cores, rank 0, N=1.  `c3` (unless --no-c3) is a bounded run of BASELINE configs[2]: full
+the host cores, rank 0, N=1.  `c4` (unless --no-c3) is a bounded env-step leg at BASELINE configs[3]'s shape with the
+job-wide env count fixed (16 UAV x 256 PoI x 8192 envs / N per GPU: strong scaling).  `c3` (unless --no-c3) is a bounded run of BASELINE configs[2]: full
 MAPPO iterations (policy-driven rollout + HIP GAE + PPO epochs) at the same shape, with the RCCL
 gradient all-reduce when N>1; it never affects `value`.
 """
@@ -201,6 +202,59 @@ def bench_mappo(args):
     if rank == 0:
         print(json.dumps(res), flush=True)
     return res
+
+
+def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, launches=12, warm=3):
+    """Bounded env-step leg at another BASELINE shape with the JOB-WIDE env count fixed (strong scaling): BASELINE
+    configs[3] is 16 UAV x 256 PoI x 8192 envs over the GPUs of the job, i.e. 8192 / world envs per GPU, no data-path
+    collective.  `launches` fused launches of T steps (in-kernel action stream), HIP-event timed; value = job-wide
+    agent-env-steps / max-over-ranks wall time."""
+    import dcc_hip
+    if E_total % world:
+        raise ValueError("%d envs do not divide over %d GPUs" % (E_total, world))
+    E = E_total // world
+    poi_all = np.load(os.path.join(PKG, "envs", "mpe", "pos_pois.npy"))
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi_all[:M], 0.2, 0.4, 0.95, 0.0, device=local_dev)
+    env.reset()
+    out = env.alloc_out(T)
+    dev = torch.device("cuda", local_dev)
+
+    def go(n, step0, events=None):
+        for i in range(n):
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            env.rollout(T, seed=0, step0=step0 + i * T, env0=rank * E, env_total=E_total, out=out)
+            if events is not None:
+                e1.record(); events.append((e0, e1))
+
+    go(warm, 0)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = []
+    t0 = time.perf_counter()
+    go(launches, warm * T, ev)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = [a.elapsed_time(b) for a, b in ev]
+    bstep = dcc_hip.bytes_per_step(N, M, with_actions=False, with_obs=True)
+    ach = bstep * E * T / (sum(ms) / len(ms) * 1e-3) / 1e9
+    env.close()
+    del env, out
+    torch.cuda.empty_cache()
+    return {"workload": "c4 (BASELINE configs[3]): %d UAV x %d PoI x %d envs job-wide = %d per GPU over %d GPU(s), random-action "
+                        "env-step kernel, %d fused launches x %d steps, actions drawn in-kernel, obs written" % (N, M, E_total, E, world, launches, T),
+            "value": E_total * N * T * launches / dt, "unit": "agent-env-steps/s", "scaling": "strong", "n_gpus": world,
+            "envs_per_gpu": E, "us_per_step": sum(ms) / len(ms) / T * 1e3,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "bytes_per_env_step": bstep, "launch_ms_avg": sum(ms) / len(ms), "launches_timed": len(ms)}}
 
 
 def _free_port():
@@ -411,6 +465,10 @@ def main():
                 os._exit(0)
 
         threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            res["c4"] = env_shape_leg(16, 256, 8192, world, rank, local_dev, dist, backend)
+        except Exception as e:  # noqa: BLE001
+            res["c4"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         try:
             res["c3"] = mappo_iterations(args, args.c3_iters)
         except Exception as e:  # noqa: BLE001

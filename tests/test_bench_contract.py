@@ -52,6 +52,9 @@ def test_the_drivers_exact_command_is_a_real_measurement():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e5 and "sample" in c
     assert d["value"] > 50e6                          # the north-star floor, by a wide margin
+    c4 = d["c4"]
+    assert "error" not in c4, c4
+    assert c4["scaling"] == "strong" and c4["envs_per_gpu"] == 8192 and c4["value"] > 1e8 and 0.3 < c4["roofline"]["frac"] < 1.0
     c3 = d["c3"]
     assert "error" not in c3, c3
     assert c3["value"] > 1e6 and c3["iters_timed"] == 2 and c3["rollout_s_per_iter"] > 0 and c3["update_s_per_iter"] > 0
@@ -61,7 +64,7 @@ def test_the_drivers_exact_command_is_a_real_measurement():
 def test_no_flags_defaults_finish_quickly_and_match_the_driver_shape():
     d = _run(["--no-c3", "--no-cpu-baseline"])
     _check_line(d, 20, 5)
-    assert "c3" not in d and "cpu_baseline" not in d
+    assert "c3" not in d and "c4" not in d and "cpu_baseline" not in d
 
 
 def test_gpus_2_launches_itself():
@@ -80,6 +83,7 @@ def test_gpus_2_launches_itself():
     assert abs(d["value"] - 2 * 1024 * 8 * 4 * 150 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
     assert d["roofline"]["launches_timed"] == 8
     assert "error" not in d["c3"], d["c3"]
+    assert "error" not in d["c4"] and d["c4"]["envs_per_gpu"] == 4096 and d["c4"]["n_gpus"] == 2, d["c4"]
     assert d["c3"]["n_gpus"] == 2 and d["c3"]["grad_allreduce"].endswith(" x2")
 
 
