@@ -6,7 +6,7 @@
 `relu_ln_head(...)`   the last block's tail fused with the narrow Linear after it (Gaussian mean, value head).
 `actor_l1(...)`       the actor's whole first block from the compact features (structured.py) -- the pre-activation
                       never reaches memory in either direction.
-Both fall back to the plain torch formulation when the tensors are not float32 CUDA tensors (CPU tests, bf16
+All fall back to the plain torch formulation when the tensors are not float32 CUDA tensors (CPU tests,
 autocast) or the shape has no compiled variant; on a GPU box the library itself must load (dcc_hip raises).
 """
 import torch

@@ -333,8 +333,7 @@ class MAPPOTrainer:
             if self.update_chunk_steps <= 0:   # rows are regenerated per chunk: keep them small; features are tiny
                 self.update_chunk_steps = buffer.episode_length if getattr(buffer, "structured", False) else 10
             if getattr(buffer, "structured", False):
-                # per-chunk state features: parameter-free, shared by all epochs, recomputed IN PLACE after a rollout.
-                # Done here (not lazily inside the epoch) because a replayed epoch graph runs no Python.
+                # per-chunk state features: parameter-free, shared by all epochs, recomputed IN PLACE after a rollout
                 T, step = buffer.episode_length, max(1, int(self.update_chunk_steps))
                 for t0 in range(0, T, step):
                     buffer.features_rows(t0, min(T, t0 + step))

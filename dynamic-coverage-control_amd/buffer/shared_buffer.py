@@ -139,8 +139,8 @@ class SharedReplayBuffer(object):
 
     def features_rows(self, t0, t1):
         """Features of slots t0..t1-1 flattened over (step, env).  They do not depend on the parameters, so all PPO
-        epochs of an iteration share them; the buffers are persistent (recomputed in place after every rollout), which
-        keeps their addresses valid for a captured hipGraph of the epoch."""
+        epochs of an iteration share them; the buffers are persistent (recomputed in place after every rollout: no
+        allocation per iteration)."""
         key = (t0, t1)
         f = self._feat_cache.get(key)
         if f is None or key not in self._feat_valid:
