@@ -728,10 +728,10 @@ __device__ __forceinline__ void row_stats_full(const float (&a)[4], float eps, f
 template <int NR>
 __device__ __forceinline__ void env_row_z(const EnvIn<NR>& in, const int i, const int lane, const float (&w)[EnvIn<NR>::HD][4],
                                           const bool has_stats, float invD, float eps_in, const float (&sv)[4],
-                                          const float (&cv)[4], float (&zr)[4], float& mean_in, float& rstd_in) {
+                                          const float (&cv)[4], float (&zr)[4], float& mean_in, float& rstd_in, float& hv) {
     constexpr int HD = EnvIn<NR>::HD;
     const int f = i * HD + lane;
-    float hv = __shfl(in.h[0], f & 63, 64);
+    hv = __shfl(in.h[0], f & 63, 64);
 #pragma unroll
     for (int r = 1; r < EnvIn<NR>::HW; ++r) {
         const float t = __shfl(in.h[r], f & 63, 64);
@@ -781,8 +781,8 @@ __global__ __launch_bounds__(kBlock, DCC_L1F_WAVES) void actor_l1_fwd_env_k(cons
         float* hrow = h + e * NR * H + cb;
 #pragma unroll 1
         for (int i = 0; i < NR; ++i) {
-            float a[4], mi, ri;
-            env_row_z<NR>(cur, i, lane, w, has_stats, invD, eps_in, sv, cv, a, mi, ri);
+            float a[4], mi, ri, hv;
+            env_row_z<NR>(cur, i, lane, w, has_stats, invD, eps_in, sv, cv, a, mi, ri, hv);
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = fmaxf(a[j], 0.f);
             float mean, rstd;
@@ -796,8 +796,10 @@ __global__ __launch_bounds__(kBlock, DCC_L1F_WAVES) void actor_l1_fwd_env_k(cons
     }
 }
 
-// Backward, q-storing form (dWh = q^T head is the caller's GEMM): the dh rows are streamed three rows ahead.
-template <int NR>
+// Backward; the dh rows are streamed three rows ahead.  ACCW = false: q = rstd_in * dz is stored and dWh = q^T head is the
+// caller's GEMM; ACCW = true: dWh is accumulated in registers next to Wh^T (no [rows, H] write, no GEMM, no reduction pass
+// over q), per-wave partials reduced in a fixed order like the other parameter gradients.
+template <int NR, bool ACCW>
 __global__ __launch_bounds__(kBlock, DCC_L1B_WAVES) void actor_l1_bwd_env_k(const float* __restrict__ head, const float* __restrict__ G,
                                                                 const double* __restrict__ stats, const float* __restrict__ Wh,
                                                                 const float* __restrict__ s, const float* __restrict__ c,
@@ -811,6 +813,9 @@ __global__ __launch_bounds__(kBlock, DCC_L1B_WAVES) void actor_l1_bwd_env_k(cons
     const int cb = lane * 4;
     float g[4], sv[4], cv[4], w[HD][4];
     float acc_g[4] = {0, 0, 0, 0}, acc_b[4] = {0, 0, 0, 0}, acc_s[4] = {0, 0, 0, 0}, acc_c[4] = {0, 0, 0, 0};
+    float aw[ACCW ? HD : 1][4];
+#pragma unroll
+    for (int k = 0; k < (ACCW ? HD : 1); ++k) aw[k][0] = aw[k][1] = aw[k][2] = aw[k][3] = 0.f;
     ld<4>(gamma + cb, g); ld<4>(s + cb, sv); ld<4>(c + cb, cv);
 #pragma unroll
     for (int k = 0; k < HD; ++k)
@@ -834,15 +839,15 @@ __global__ __launch_bounds__(kBlock, DCC_L1B_WAVES) void actor_l1_bwd_env_k(cons
     for (long long e = gw; e < n; e += nw) {
         if (e + nw < n) fetch_env<NR>(head, stats, G, e + nw, lane, nxt);
         float dGv[4] = {0.f, 0.f, 0.f, 0.f};
-        float* qrow = dq + e * NR * H + cb;
+        float* qrow = ACCW ? nullptr : dq + e * NR * H + cb;
 #pragma unroll 1
         for (int i = 0; i < NR; ++i) {
             float d[4], zr[4], a[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { d[j] = nd[0][j]; nd[0][j] = nd[1][j]; nd[1][j] = nd[2][j]; }
             fetch_dh(nd[2]);                                   // row t+3
-            float mean_in, rstd_in;
-            env_row_z<NR>(cur, i, lane, w, has_stats, invD, eps_in, sv, cv, zr, mean_in, rstd_in);
+            float mean_in, rstd_in, hv;
+            env_row_z<NR>(cur, i, lane, w, has_stats, invD, eps_in, sv, cv, zr, mean_in, rstd_in, hv);
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = fmaxf(zr[j], 0.f);
             float mean, rstd;
@@ -868,13 +873,29 @@ __global__ __launch_bounds__(kBlock, DCC_L1B_WAVES) void actor_l1_bwd_env_k(cons
                 acc_s[j] -= mean_in * q[j];
                 acc_c[j] += d[j];
             }
-            st<4>(qrow + (long long)i * H, q);
+            if constexpr (ACCW) {
+#pragma unroll
+                for (int k = 0; k < HD; ++k) {
+                    const float x = readlane_f(hv, k);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) aw[k][j] += q[j] * x;
+                }
+            } else {
+                st<4>(qrow + (long long)i * H, q);
+            }
         }
         st<4>(dG + e * H + cb, dGv);
         cur = nxt;
     }
-    float* wv = ws + gw * 4 * H;     // per-wave partials [ds | dc | dgamma | dbeta] (the HDP = 0 layout of l1_reduce_k)
-    st<4>(wv + cb, acc_s); st<4>(wv + H + cb, acc_c); st<4>(wv + 2 * H + cb, acc_g); st<4>(wv + 3 * H + cb, acc_b);
+    // per-wave partials in l1_reduce_k's layout: [dWt rows (HD x H, ACCW only) | ds | dc | dgamma | dbeta]
+    constexpr int KW = ACCW ? HD : 0;
+    float* wv = ws + gw * (KW + 4) * H;
+    if constexpr (ACCW) {
+#pragma unroll
+        for (int k = 0; k < HD; ++k) st<4>(wv + k * H + cb, aw[k]);
+    }
+    st<4>(wv + KW * H + cb, acc_s); st<4>(wv + (KW + 1) * H + cb, acc_c); st<4>(wv + (KW + 2) * H + cb, acc_g);
+    st<4>(wv + (KW + 3) * H + cb, acc_b);
 }
 
 // per-wave partial vector of the L1 backward: [dWt (HDP*H) | ds (H) | dc (H) | dgamma (H) | dbeta (H)].
@@ -1281,25 +1302,28 @@ DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* st
     const int grid = (int)waves_for(n, kL1Blocks);
     int hdp_used = hdp;
     int grid_used = grid;
-    if (dq) {   // two-kernel variant: light registers -> full occupancy, so use the larger grid too
-        if (sh.vec == 4 && !aligned16(dq)) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
+    const bool env_ok = H == 256 && HD == 4 + 2 * (N - 1) && (N == 8 || N == 4) && aligned16(stats) && aligned16(head);
+    bool done_launch = false;
+    if (env_ok) {   // BASELINE sizes: actor_l1_bwd_env_k (Wh^T in registers, env-ahead prefetch), grid = what is co-resident
+        if (dq && sh.vec == 4 && !aligned16(dq)) return dcc_fail(kEINVAL, std::string(__func__) + ": dq must be 16-byte aligned");
+        static int res[4] = {0, 0, 0, 0};
+        const int v = (N == 8 ? 0 : 1) + (dq ? 0 : 2);
+        const void* fns[4] = {reinterpret_cast<const void*>(&actor_l1_bwd_env_k<8, false>), reinterpret_cast<const void*>(&actor_l1_bwd_env_k<4, false>),
+                              reinterpret_cast<const void*>(&actor_l1_bwd_env_k<8, true>), reinterpret_cast<const void*>(&actor_l1_bwd_env_k<4, true>)};
+        if (!res[v]) res[v] = resident_blocks(fns[v]);
+        grid_used = (int)waves_for(n, dq ? kL1Blocks * 2 : kL1Blocks);       // bounded by the workspace the caller sized
+        if (res[v] < grid_used) grid_used = res[v];
+#define L1B_ENV(NRV, ACC) hipLaunchKernelGGL((actor_l1_bwd_env_k<NRV, ACC>), dim3(grid_used), dim3(kBlock), 0, st_, head, G, stats, Wh, s, c, \
+                                             gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n)
+        if (N == 8) { if (dq) L1B_ENV(8, false); else L1B_ENV(8, true); }
+        else { if (dq) L1B_ENV(4, false); else L1B_ENV(4, true); }
+#undef L1B_ENV
+        hdp_used = dq ? 0 : HD;
+        done_launch = true;
+    } else if (dq) {   // two-kernel variant: light registers -> full occupancy, so use the larger grid too
+        if (sh.vec == 4 && !aligned16(dq)) return dcc_fail(kEINVAL, std::string(__func__) + ": dq must be 16-byte aligned");
         grid_used = (int)waves_for(n, kL1Blocks * 2);
-        if (H == 256 && HD == 4 + 2 * (N - 1) && (N == 8 || N == 4) && aligned16(stats) && aligned16(head)) {
-            static int res8 = 0, res4 = 0;      // BASELINE sizes: actor_l1_bwd_env_k, grid = what is co-resident
-            if (N == 8) {
-                if (!res8) res8 = resident_blocks(reinterpret_cast<const void*>(&actor_l1_bwd_env_k<8>));
-                if (res8 < grid_used) grid_used = res8;
-                hipLaunchKernelGGL((actor_l1_bwd_env_k<8>), dim3(grid_used), dim3(kBlock), 0, st_, head, G, stats, Wh, s, c, gamma, dh,
-                                   eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n);
-            } else {
-                if (!res4) res4 = resident_blocks(reinterpret_cast<const void*>(&actor_l1_bwd_env_k<4>));
-                if (res4 < grid_used) grid_used = res4;
-                hipLaunchKernelGGL((actor_l1_bwd_env_k<4>), dim3(grid_used), dim3(kBlock), 0, st_, head, G, stats, Wh, s, c, gamma, dh,
-                                   eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n);
-            }
-        } else {
-            launch_l1_bwd<0>(sh, grid_used, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H);
-        }
+        launch_l1_bwd<0>(sh, grid_used, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H);
     } else {
         switch (hdp) {
             case 0: launch_l1_bwd<0>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
@@ -1309,7 +1333,8 @@ DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* st
             default: launch_l1_bwd<40>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
         }
     }
-    if (dq) hdp_used = 0;
+    (void)done_launch;
+    if (!env_ok && dq) hdp_used = 0;
     const int P = (hdp_used + 4) * H;
     const long long nseg = reduce_stage1(workspace, (long long)grid_used * kWavesPerBlock, P, P, st_);
     hipLaunchKernelGGL(l1_reduce_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace, nseg,

@@ -35,7 +35,7 @@ rows = [
     ("relu_ln_head_fwd", lambda: dcc_hip.relu_ln_head_fwd(z, bias, g, b, 1e-5, Wo, bo), R * H * 4),
     ("relu_ln_head_bwd", lambda: dcc_hip.relu_ln_head_bwd(z, bias, g, b, 1e-5, Wo, dy), 2 * R * H * 4),
     ("actor_l1_fwd", lambda: dcc_hip.actor_l1_fwd(head, G, stats, Wh, s, c, g, b, 1e-5, 1e-5, 338), R * H * 4 + n * H * 4 + R * HD * 4),
-    ("actor_l1_bwd (1 kernel)", lambda: dcc_hip.actor_l1_bwd(head, G, stats, Wh, s, c, g, dh, 1e-5, 1e-5, 338, two_kernel=False), R * H * 4 + 2 * n * H * 4 + R * HD * 4),
+    ("actor_l1_bwd (1 kernel: dWh in registers)", lambda: dcc_hip.actor_l1_bwd(head, G, stats, Wh, s, c, g, dh, 1e-5, 1e-5, 338, two_kernel=False), R * H * 4 + 2 * n * H * 4 + R * HD * 4),
     ("actor_l1_bwd (q + GEMM)", lambda: dcc_hip.actor_l1_bwd(head, G, stats, Wh, s, c, g, dh, 1e-5, 1e-5, 338, two_kernel=True), 3 * R * H * 4 + 2 * n * H * 4 + 2 * R * HD * 4),
 ]
 for name, fn, nbytes in rows:
