@@ -63,6 +63,11 @@ __device__ __forceinline__ void st(float* __restrict__ p, const float (&v)[VEC])
     }
 }
 
+// 1 / sqrt(x) as ONE v_rsq_f32 (1 ulp; x = variance + eps is O(1e-5 .. 1e3) here, far from the denormal range).  The
+// IEEE-exact `1.0f / sqrtf(x)` is ~30 instructions under -fno-fast-math, once or twice per row of every kernel here.  Every
+// forward and its backward use this same function, so a backward's recomputed activations are the forward's.
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+
 // ReLU + LayerNorm statistics of one row held in a[VPL][VEC] (already ReLU'd, zeros in masked slots).
 template <int VEC, int VPL>
 __device__ __forceinline__ void row_stats(const float (&a)[VPL][VEC], const bool (&ok)[VPL], float invH, float eps,
@@ -80,7 +85,7 @@ __device__ __forceinline__ void row_stats(const float (&a)[VPL][VEC], const bool
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { const float d = a[v][j] - mean; q += d * d; }
         }
-    rstd = 1.0f / sqrtf(wave_sum(q) * invH + eps);
+    rstd = fast_rsqrt(wave_sum(q) * invH + eps);
 }
 
 // ---- h = LayerNorm(ReLU(z)) -------------------------------------------------------------------------------------
@@ -707,10 +712,6 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
-// 1 / sqrt(x) as ONE v_rsq_f32 (1 ulp; x = variance + eps is O(1e-5 .. 1e3) here, far from the denormal range).  The
-// IEEE-exact `1.0f / sqrtf(x)` of the generic kernels is ~30 instructions under -fno-fast-math, twice per row.  Forward and
-// backward of the env kernels use the same function, so the backward's recomputed activations are the forward's.
-__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 
 // ReLU + LayerNorm moments of one full row of 256 (float4 per lane, every lane valid)
 __device__ __forceinline__ void row_stats_full(const float (&a)[4], float eps, float& mean, float& rstd) {
