@@ -42,7 +42,28 @@ assert infos[0][0] == infos[0][0]      # rollout statistics are all-reduced: sam
 rs = [torch.tensor([infos[-1][0]["reward"]], dtype=torch.float64, device=ptu.device) for _ in range(2)]
 dist.all_gather(rs, rs[0].clone())
 assert torch.equal(rs[0], rs[1])
+# per-rank resume state (advisor finding of round 1: every rank used to restore rank 0's RNG streams): the checkpoint is
+# written collectively, a fresh Learner of each rank restores ITS OWN streams and env shard, and the next rollout of the
+# resumed job equals the next rollout of the original one on every rank
+import tempfile  # noqa: E402
+ckdir = os.environ.get("DCC_TEST_CKPT_DIR") or tempfile.gettempdir()
+ck = os.path.join(ckdir, "dist_resume_test.pt")
+lr.cur_iter = 3
+lr.save_checkpoint(ck)
+dist.barrier()
+rng_here = torch.cuda.get_rng_state(ptu.device).clone()
+nxt = lr.rollout(lr.rl_buffer, lr.train_envs)
+acts = lr.rl_buffer.actions.clone()
+lr2 = Learner(Namespace(**dict(cfg, seed=77)))
+lr2.load_checkpoint(ck)
+assert lr2.start_iter == 4 and torch.equal(torch.cuda.get_rng_state(ptu.device), rng_here)
+nxt2 = lr2.rollout(lr2.rl_buffer, lr2.train_envs)
+assert nxt2 == nxt and torch.equal(lr2.rl_buffer.actions, acts)
+a_sum = [torch.zeros(1, dtype=torch.float64, device=ptu.device) for _ in range(2)]
+dist.all_gather(a_sum, acts.double().sum().reshape(1))
+assert not torch.equal(a_sum[0], a_sum[1]), "the ranks must keep decorrelated action noise after a resume"
 if lr.rank == 0:
+    os.remove(ck)
     print("DIST_GPU_OK graphs=%d reward=%.3f" % (len(lr._graphs), infos[-1][0]["reward"]))
 dist.barrier()
 dist.destroy_process_group()
