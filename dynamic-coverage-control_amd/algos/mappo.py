@@ -22,7 +22,6 @@ import os
 import pickle
 
 import torch
-import torch.nn as nn
 
 import utils.pytorch_utils as ptu
 from algos.algo_utils import fused
