@@ -218,6 +218,7 @@ struct ActFetch {
     float2 f[RF], fn[RF];
     double2 d[ACT_RD], dn[ACT_RD];
     int kc, r_sel, s_sel;
+    bool primed;      // the first chunk's loads were issued before the step loop (prefetch_actions)
 };
 
 // Per-step outputs of one env, handed from the physics wave to the observation wave (role-specialised kernel):
@@ -340,7 +341,7 @@ __device__ __forceinline__ void env_physics_step(const KParams& p, const int env
             // consume below finds loads that were issued a whole chunk of steps ago.  float64 actions (twice the
             // registers) are loaded and consumed on the spot.
             constexpr bool AHEAD = (ACT == 0);
-            if (!AHEAD || k == 0) issue(k);
+            if ((!AHEAD || k == 0) && !(k == 0 && af.primed)) issue(k);
             // consume inside this branch: the vmcnt wait is paid only on chunk boundaries
 #pragma unroll
             for (int rr = 0; rr < ACT_R; ++rr) {
@@ -687,7 +688,31 @@ __device__ __forceinline__ void init_act(ActFetch<RF>& af) {
     for (int rr = 0; rr < RF; ++rr) af.f[rr] = af.fn[rr] = make_float2(0.f, 0.f);
 #pragma unroll
     for (int rr = 0; rr < ACT_RD; ++rr) af.d[rr] = af.dn[rr] = make_double2(0.0, 0.0);
-    af.kc = 0; af.r_sel = 0; af.s_sel = 0;
+    af.kc = 0; af.r_sel = 0; af.s_sel = 0; af.primed = false;
+}
+
+// Issue the loads of the first action chunk (the same addresses env_physics_step's `issue(0)` would load) before anything
+// else of the launch is waited for; the step at k = 0 then finds them in flight (af.primed).
+template <int PPL, int ACT, bool FORCE, int NC>
+__device__ __forceinline__ void prefetch_actions(const KParams& p, const int env, const int lane, ActFetch<act_rf<PPL, FORCE>()>& af) {
+    if constexpr (ACT != 2) {
+        constexpr bool SPEC = NC > 0;
+        const int N = SPEC ? NC : p.N;
+        constexpr int ACT_R = (ACT == 1) ? ACT_RD : act_rf<PPL, FORCE>();
+        const int steps_per_load = 64 / N;
+        const int my_s = SPEC ? (lane / (SPEC ? NC : 1)) : (int)(((unsigned)lane * p.magicN) >> 20);
+        const int my_i = lane - my_s * N;
+#pragma unroll
+        for (int rr = 0; rr < ACT_R; ++rr) {
+            const int ks = rr * steps_per_load + my_s;
+            if (my_s < steps_per_load && ks < p.K) {
+                const size_t ai = ((size_t)ks * p.E + env) * N + my_i;
+                if (ACT == 1) af.dn[rr] = reinterpret_cast<const double2*>(p.actions)[ai];
+                else af.fn[rr] = reinterpret_cast<const float2*>(p.actions)[ai];
+            }
+        }
+        af.primed = true;
+    }
 }
 
 // ---- kernel 1: fused -- one env per wavefront does physics AND its own observation stores ------------
@@ -711,18 +736,24 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? (PPL >= 4 ? 2 : 3)
     double2* avel = apos + N;
     float* stg = reinterpret_cast<float*>(avel + N);
 
-    for (int j = threadIdx.x; j < M; j += kBlock) s_poi[j] = p.poi[j];
-    __syncthreads();
+    // <= 4 PoIs per lane: their coordinates live in registers, read straight from the (L2-resident) table -- no LDS
+    // staging, no workgroup barrier on the way to the first step (the K = 1 launches of a policy-driven rollout are pure
+    // latency: 9.6 -> 8.x us).  More PoIs per lane: the table is staged in LDS and read from there.
+    if (!PoiLane<PPL>::REG) {
+        for (int j = threadIdx.x; j < M; j += kBlock) s_poi[j] = p.poi[j];
+        __syncthreads();
+    }
     if (env >= p.E) return;
 
     EnvRegs<PPL> r;
     PoiLane<PPL> poi;
-    poi.init(s_poi, lane, M);
+    ActFetch<act_rf<PPL, FORCE>()> af;
+    init_act(af);
+    if (p.mode == 0) prefetch_actions<PPL, ACT, FORCE, NC>(p, env, lane, af);   // in flight while the state loads are waited for
+    poi.init(PoiLane<PPL>::REG ? p.poi : s_poi, lane, M);
     load_env_state<PPL>(p, env, lane, N, M, r);
     if (lane < N) { apos[lane] = make_double2(r.px, r.py); avel[lane] = make_double2(r.vx, r.vy); }
     wave_fence();
-    ActFetch<act_rf<PPL, FORCE>()> af;
-    init_act(af);
 
     for (int k = 0; k < p.K; ++k) {
         if (p.mode == 0) env_physics_step<PPL, ACT, FORCE, NC, MC>(p, env, k, lane, r, af, poi, apos, apos, avel);
@@ -788,18 +819,42 @@ struct FeatParams {
     float* xa; float* xc;       // per-env GEMM inputs [energy | done | 1 | 0..] and [head_0..head_{N-1} | energy | done | 1 | 0..]
     int ka, kc;                 // their row lengths (multiples of 8 floats)
     int n, N, M; float m_energy;
+    int stage;                  // 1: the N*HD head values of a state are assembled in LDS and stored as float4 runs
 };
+
+// Wave-wide float64 sum on the VALU (DPP moves of the two 32-bit halves: 4 steps leave every 16-lane row with its row sum,
+// the 4 row sums are combined through readlane) instead of 6 dependent ds_bpermute round trips per reduction: the feature
+// kernel is a chain of 2N + 2 such reductions per state and purely latency-bound (17 us per 4096 states before).
+// Deterministic, but a different summation order than wave_sum_f64 (which the env step keeps for its reward).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_f64_dpp(double v) {
+    v += dpp_mov_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);   // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);   // row_mirror
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
 
 // PPL PoIs per lane, loaded ONCE into registers: the PoI coordinates / energies / done flags are re-used by every agent row
 // and both moment passes (read from global memory inside the agent loop they cost a dependent L2 round trip per agent and
 // pass: 16 at 8 UAVs, which made this kernel 30 us per 4096 states).
 template <int PPL>
 __global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatParams p) {
+    extern __shared__ __attribute__((aligned(16))) float feat_lds[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = blockIdx.x * kWavesPerBlock + wid;
     if (n >= p.n) return;
     const int N = p.N, M = p.M, HD = 4 + 2 * (N - 1), D = HD + 5 * M;
+    // The head values of agent i come from different lanes (own vel / pos from lane i, the relative position of UAV a from
+    // lane a): written straight to HBM they are 4-byte stores at an 8-byte stride, 4 store instructions per agent that
+    // each touch a cache line partially.  Staged per wave in LDS (N*HD floats) they leave as two float4 runs per state.
+    float* hrow = p.stage ? feat_lds + (size_t)wid * N * HD : nullptr;
     double2 mp = make_double2(0.0, 0.0), mv = mp;
     if (lane < N) { mp = p.pos[(size_t)n * N + lane]; mv = p.vel[(size_t)n * N + lane]; }
     double qx[PPL], qy[PPL], enq[PPL], dnq[PPL];
@@ -826,7 +881,11 @@ __global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatPara
         const float rx = (float)(mp.x - px), ry = (float)(mp.y - py);   // what the obs row holds for agent `lane`
         const bool other = lane < N && lane != i;
         const float v0 = (float)mv.x, v1 = (float)mv.y, p0 = (float)mp.x, p1 = (float)mp.y;
-        if (p.head || p.xc) {
+        if (hrow) {
+            float* h = hrow + i * HD;
+            if (lane == i) { h[0] = v0; h[1] = v1; h[2] = p0; h[3] = p1; }
+            if (other) { const int k = lane < i ? lane : lane - 1; h[4 + 2 * k] = rx; h[5 + 2 * k] = ry; }
+        } else if (p.head || p.xc) {
             float* h = p.head ? p.head + ((size_t)n * N + i) * HD : nullptr;
             float* x = p.xc ? p.xc + (size_t)n * p.kc + i * HD : nullptr;
             if (lane == i) {
@@ -850,7 +909,7 @@ __global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatPara
             fx[t] = (float)(qx[t] - px); fy[t] = (float)(qy[t] - py);
             if (t * 64 + lane < M) s += (double)fx[t] + (double)fy[t] + enq[t] + me + dnq[t];
         }
-        const double mean = wave_sum_f64(s) / (double)D;
+        const double mean = wave_sum_f64_dpp(s) / (double)D;
         double m2 = 0.0;
         auto sq = [mean](double x) { const double d = x - mean; return d * d; };
         if (lane == i) m2 = sq((double)v0) + sq((double)v1) + sq((double)p0) + sq((double)p1);
@@ -858,16 +917,28 @@ __global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatPara
 #pragma unroll
         for (int t = 0; t < PPL; ++t)
             if (t * 64 + lane < M) m2 += sq((double)fx[t]) + sq((double)fy[t]) + sq(enq[t]) + sq(me) + sq(dnq[t]);
-        m2 = wave_sum_f64(m2);
+        m2 = wave_sum_f64_dpp(m2);
         if (lane == 0 && p.stats) { p.stats[((size_t)n * N + i) * 2] = mean; p.stats[((size_t)n * N + i) * 2 + 1] = m2; }
         if (lane == i) { my_mean = mean; my_m2 = m2; }
+    }
+    if (hrow) {     // N*HD = 2N(N+1) floats: a multiple of 4, rows of head / xc start 16-byte aligned
+        wave_fence();
+        const int n4 = (N * HD) >> 2;
+        const float4* src = reinterpret_cast<const float4*>(hrow);
+        float4* dh = p.head ? reinterpret_cast<float4*>(p.head + (size_t)n * N * HD) : nullptr;
+        float4* dx = p.xc ? reinterpret_cast<float4*>(p.xc + (size_t)n * p.kc) : nullptr;
+        for (int v = lane; v < n4; v += 64) {
+            const float4 t = src[v];
+            if (dh) dh[v] = t;
+            if (dx) dx[v] = t;
+        }
     }
     if (p.cstats) {
         // moments of the centralised row = concatenation of the N agent rows (equal widths D): pooled mean, and
         // sum of squared deviations by the parallel-variance identity
-        const double mean_e = wave_sum_f64(lane < N ? my_mean : 0.0) / (double)N;
+        const double mean_e = wave_sum_f64_dpp(lane < N ? my_mean : 0.0) / (double)N;
         const double dm = my_mean - mean_e;
-        const double m2_e = wave_sum_f64(lane < N ? my_m2 + (double)D * dm * dm : 0.0);
+        const double m2_e = wave_sum_f64_dpp(lane < N ? my_m2 + (double)D * dm * dm : 0.0);
         if (lane == 0) { p.cstats[(size_t)n * 2] = mean_e; p.cstats[(size_t)n * 2 + 1] = m2_e; }
     }
 }
@@ -1595,12 +1666,17 @@ int dcc_obs_features_x(dcc_env* e, int64_t n, const double* pos, const double* v
     p.kc = (p.N * (4 + 2 * (p.N - 1)) + 2 * p.M + 1 + 7) / 8 * 8;
     const int grid = (int)((n + kWavesPerBlock - 1) / kWavesPerBlock);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t head_floats = (size_t)p.N * (4 + 2 * (p.N - 1));
+    size_t lds = (size_t)kWavesPerBlock * head_floats * sizeof(float);
+    const auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    p.stage = (head || xc) && lds <= 48 * 1024 && a16(head) && a16(xc);
+    if (!p.stage) lds = 0;
     switch (e->PPL) {
-        case 1: hipLaunchKernelGGL(dcc_obs_features_kernel<1>, dim3(grid), dim3(kBlock), 0, s, p); break;
-        case 2: hipLaunchKernelGGL(dcc_obs_features_kernel<2>, dim3(grid), dim3(kBlock), 0, s, p); break;
-        case 4: hipLaunchKernelGGL(dcc_obs_features_kernel<4>, dim3(grid), dim3(kBlock), 0, s, p); break;
-        case 8: hipLaunchKernelGGL(dcc_obs_features_kernel<8>, dim3(grid), dim3(kBlock), 0, s, p); break;
-        default: hipLaunchKernelGGL(dcc_obs_features_kernel<16>, dim3(grid), dim3(kBlock), 0, s, p); break;
+        case 1: hipLaunchKernelGGL(dcc_obs_features_kernel<1>, dim3(grid), dim3(kBlock), lds, s, p); break;
+        case 2: hipLaunchKernelGGL(dcc_obs_features_kernel<2>, dim3(grid), dim3(kBlock), lds, s, p); break;
+        case 4: hipLaunchKernelGGL(dcc_obs_features_kernel<4>, dim3(grid), dim3(kBlock), lds, s, p); break;
+        case 8: hipLaunchKernelGGL(dcc_obs_features_kernel<8>, dim3(grid), dim3(kBlock), lds, s, p); break;
+        default: hipLaunchKernelGGL(dcc_obs_features_kernel<16>, dim3(grid), dim3(kBlock), lds, s, p); break;
     }
     HIP_TRY(hipGetLastError());
     return DCC_OK;
