@@ -56,7 +56,7 @@ class _Infos:
 class HipCoverageVecEnv:
     def __init__(self, n_envs, num_agents=4, num_pois=20, r_cover=0.2, r_comm=0.4, comm_r_scale=0.95,
                  comm_force_scale=0.0, max_ep_len=150, device=None, poi_xy=None, obs_dtype=np.float32,
-                 env0=0, env_total=None, **consts):
+                 env0=0, env_total=None, reuse_host_buffers=False, **consts):
         self.n_envs, self.n_agents, self.n_pois = int(n_envs), int(num_agents), int(num_pois)
         self.max_ep_len = max_ep_len
         poi = load_pois(self.n_pois) if poi_xy is None else np.asarray(poi_xy, np.float64)
@@ -75,6 +75,11 @@ class HipCoverageVecEnv:
         self.share_observation_space = [Box(-inf, inf, (N * D,), np.float32) for _ in range(N)]
         self._out = None
         self._closed = False
+        # numpy surface: results leave the device through PINNED staging buffers (a pageable `.cpu()` of the 44 MB of
+        # observations of a c2 step runs at 1.7 GB/s = 27 ms; pinned: 33 GB/s = 1.3 ms).  reuse_host_buffers: return views of
+        # two alternating pinned sets (valid until the step after next) instead of fresh copies (+4 ms host memcpy at c2).
+        self.reuse_host_buffers = bool(reuse_host_buffers)
+        self._pin, self._flip = None, 0
 
     # ---- device surface ---------------------------------------------------------------------------
     def reset_device(self, obs_out=None):
@@ -98,9 +103,24 @@ class HipCoverageVecEnv:
         return self.env.step(actions, out)
 
     # ---- numpy surface (reference contract) ----------------------------------------------------------
+    def _host(self, tensors):
+        """Device tensors -> numpy through the pinned staging set of this call (one stream sync for all of them)."""
+        if self._pin is None:
+            E, N, D = self.n_envs, self.n_agents, self.obs_dim
+            mk = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
+            self._pin = [dict(obs=mk((E, N, D), torch.float32), reward=mk((E,), torch.float32), done=mk((E,), torch.uint8),
+                              coverage=mk((E,), torch.float32)) for _ in range(2)]
+        pin = self._pin[self._flip]
+        self._flip ^= 1
+        for k, t in tensors.items():
+            pin[k].copy_(t, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        take = (lambda a: a) if self.reuse_host_buffers else (lambda a: a.copy())
+        return {k: take(pin[k].numpy()) for k in tensors}
+
     def reset(self):
-        obs = self.env.reset()
-        return obs.cpu().numpy().astype(self.obs_dtype, copy=False)
+        obs = self._host(dict(obs=self.env.reset()))["obs"]
+        return obs.astype(self.obs_dtype, copy=False)
 
     def step(self, actions):
         a = np.ascontiguousarray(actions)
@@ -109,13 +129,14 @@ class HipCoverageVecEnv:
         if a.shape != (self.n_envs, self.n_agents, 2):
             raise ValueError("actions must be [n_envs, n_agents, 2], got %s" % (a.shape,))
         out = self.step_device(torch.from_numpy(a).to(self.device))   # a copy: the caller's array is never mutated
-        obs = out["obs"].cpu().numpy().astype(self.obs_dtype, copy=False)
-        rew = out["reward"].cpu().numpy().astype(np.float64)
-        done = out["done"].cpu().numpy().astype(bool)
+        h = self._host({k: out[k] for k in ("obs", "reward", "done", "coverage")})
+        obs = h["obs"].astype(self.obs_dtype, copy=False)
+        rew = h["reward"].astype(np.float64)
+        done = h["done"].astype(bool)
         E, N = self.n_envs, self.n_agents
         rewards = np.repeat(rew[:, None, None], N, axis=1)               # [E,N,1]  (wrappers.py:165)
         dones = np.repeat(done[:, None], N, axis=1)                      # [E,N]
-        return obs, rewards, dones, _Infos(out["coverage"].cpu().numpy())
+        return obs, rewards, dones, _Infos(h["coverage"] if not self.reuse_host_buffers else h["coverage"].copy())
 
     def step_async(self, actions):
         self._pending = actions

@@ -47,6 +47,24 @@ def test_vec_env_numpy_surface_matches_reference_contract():
     env.close()
 
 
+def test_vec_env_numpy_surface_pinned_staging_buffers():
+    """The numpy surface leaves the device through pinned staging buffers: fresh arrays by default (the reference's
+    contract), or -- reuse_host_buffers -- views of two alternating pinned sets that stay valid for one more step."""
+    from envs.hip_vec_env import HipCoverageVecEnv
+    a = np.random.RandomState(0).uniform(-1, 1, (6, 4, 2)).astype(np.float32)
+    fresh, reuse = HipCoverageVecEnv(6, 4, 20), HipCoverageVecEnv(6, 4, 20, reuse_host_buffers=True)
+    assert np.array_equal(fresh.reset(), reuse.reset())
+    o1, r1, d1, i1 = fresh.step(a); o2, r2, d2, i2 = fresh.step(a)
+    p1, q1, e1, j1 = reuse.step(a); keep = p1.copy(); p2, q2, e2, j2 = reuse.step(a)
+    assert np.array_equal(o1, keep) and np.array_equal(o2, p2) and np.array_equal(r2, q2) and np.array_equal(d2, e2)
+    assert not np.shares_memory(o1, o2) and not np.shares_memory(p1, p2)
+    assert np.array_equal(p1, keep)                       # the previous step's view is still intact after one more step
+    p3 = reuse.step(a)[0]
+    assert np.shares_memory(p3, p1)                       # ... and is recycled by the step after that
+    assert [x["coverage_rate"] for x in i2] == [x["coverage_rate"] for x in j2]
+    fresh.close(); reuse.close()
+
+
 def test_single_env_dcenv_view():
     from envs.mpe.uav_dcc import DCEnv
     z, c = load_case(os.path.join(GOLDEN, "env_n4m20_shipped.npz"))
