@@ -16,7 +16,8 @@ byte contract of SURVEY.md section 8d (11,851 B per env-step at c2).  One step i
 Prints ONE JSON line on rank 0.  `roofline` is always measured live: HIP events around every timed
 launch on the launch stream.  `cpu_baseline` times the CPU oracle (oracle/dcc_oracle.c, "port") on
 the host cores, rank 0, N=1.  `c4` (unless --no-c3) is a bounded env-step leg at BASELINE configs[3]'s shape with the
-job-wide env count fixed (16 UAV x 256 PoI x 8192 envs / N per GPU: strong scaling).  `c3` (unless --no-c3) is a bounded run of BASELINE configs[2]: full
+job-wide env count fixed (16 UAV x 256 PoI x 8192 envs / N per GPU: strong scaling), `c5` the same for configs[4]
+(32 UAV x 1024 PoI x 16384 envs / N, connectivity pull force on).  `c3` (unless --no-c3) is a bounded run of BASELINE configs[2]: full
 MAPPO iterations (policy-driven rollout + HIP GAE + PPO epochs) at the same shape, with the RCCL
 gradient all-reduce when N>1; it never affects `value`.
 """
@@ -117,6 +118,8 @@ def mappo_iterations(args, iters, warm_iters=2):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import utils.pytorch_utils as ptu
     ptu.set_gpu_mode(True, torch.cuda.current_device())
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()        # peak_hbm_gb is this leg's own peak, not that of the legs before it
     cfg = {}
     for f in ("config/env_config/dcc.yaml", "config/algo_config/mappo.yaml", "config/expt.yaml"):
         cfg.update(yaml.safe_load(open(os.path.join(PKG, f))))
@@ -204,7 +207,8 @@ def bench_mappo(args):
     return res
 
 
-def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, launches=12, warm=3):
+def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, launches=12, warm=3, cfs=0.0, r_comm=0.4,
+                  name="c4 (BASELINE configs[3])"):
     """Bounded env-step leg at another BASELINE shape with the JOB-WIDE env count fixed (strong scaling): BASELINE
     configs[3] is 16 UAV x 256 PoI x 8192 envs over the GPUs of the job, i.e. 8192 / world envs per GPU, no data-path
     collective.  `launches` fused launches of T steps (in-kernel action stream), HIP-event timed; value = job-wide
@@ -213,8 +217,8 @@ def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, la
     if E_total % world:
         raise ValueError("%d envs do not divide over %d GPUs" % (E_total, world))
     E = E_total // world
-    poi_all = np.load(os.path.join(PKG, "envs", "mpe", "pos_pois.npy"))
-    env = dcc_hip.HipCoverageEnv(E, N, M, poi_all[:M], 0.2, 0.4, 0.95, 0.0, device=local_dev)
+    from envs.hip_vec_env import load_pois       # the reference's PoI table (+ seeded synthetic rows beyond its 1000)
+    env = dcc_hip.HipCoverageEnv(E, N, M, load_pois(M), 0.2, r_comm, 0.95, cfs, device=local_dev)
     env.reset()
     out = env.alloc_out(T)
     dev = torch.device("cuda", local_dev)
@@ -249,8 +253,10 @@ def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, la
     env.close()
     del env, out
     torch.cuda.empty_cache()
-    return {"workload": "c4 (BASELINE configs[3]): %d UAV x %d PoI x %d envs job-wide = %d per GPU over %d GPU(s), random-action "
-                        "env-step kernel, %d fused launches x %d steps, actions drawn in-kernel, obs written" % (N, M, E_total, E, world, launches, T),
+    return {"workload": "%s: %d UAV x %d PoI x %d envs job-wide = %d per GPU over %d GPU(s), random-action env-step kernel%s, "
+                        "%d fused launches x %d steps, actions drawn in-kernel, obs written"
+                        % (name, N, M, E_total, E, world, ", connectivity pull force on (comm_force_scale %.1f, r_comm %.2f)" % (cfs, r_comm) if cfs > 0 else "",
+                           launches, T),
             "value": E_total * N * T * launches / dt, "unit": "agent-env-steps/s", "scaling": "strong", "n_gpus": world,
             "envs_per_gpu": E, "us_per_step": sum(ms) / len(ms) / T * 1e3,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -469,6 +475,11 @@ def main():
             res["c4"] = env_shape_leg(16, 256, 8192, world, rank, local_dev, dist, backend)
         except Exception as e:  # noqa: BLE001
             res["c4"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        try:   # BASELINE configs[4]: the branchy wavefront path (pull force on), 16384 envs job-wide; 664 KB of rows per env-step
+            res["c5"] = env_shape_leg(32, 1024, 16384, world, rank, local_dev, dist, backend, T=4, launches=8, warm=2, cfs=0.5,
+                                      r_comm=0.1, name="c5 (BASELINE configs[4])")
+        except Exception as e:  # noqa: BLE001
+            res["c5"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         try:
             res["c3"] = mappo_iterations(args, args.c3_iters)
         except Exception as e:  # noqa: BLE001

@@ -55,6 +55,9 @@ def test_the_drivers_exact_command_is_a_real_measurement():
     c4 = d["c4"]
     assert "error" not in c4, c4
     assert c4["scaling"] == "strong" and c4["envs_per_gpu"] == 8192 and c4["value"] > 1e8 and 0.3 < c4["roofline"]["frac"] < 1.0
+    c5 = d["c5"]
+    assert "error" not in c5, c5
+    assert c5["envs_per_gpu"] == 16384 and "pull force on" in c5["workload"] and c5["value"] > 5e7 and 0.3 < c5["roofline"]["frac"] < 1.0
     c3 = d["c3"]
     assert "error" not in c3, c3
     assert c3["value"] > 1e6 and c3["iters_timed"] == 2 and c3["rollout_s_per_iter"] > 0 and c3["update_s_per_iter"] > 0
@@ -64,7 +67,7 @@ def test_the_drivers_exact_command_is_a_real_measurement():
 def test_no_flags_defaults_finish_quickly_and_match_the_driver_shape():
     d = _run(["--no-c3", "--no-cpu-baseline"])
     _check_line(d, 20, 5)
-    assert "c3" not in d and "c4" not in d and "cpu_baseline" not in d
+    assert "c3" not in d and "c4" not in d and "c5" not in d and "cpu_baseline" not in d
 
 
 def test_gpus_2_launches_itself():
