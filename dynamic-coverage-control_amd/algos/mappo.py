@@ -331,6 +331,15 @@ class MAPPOTrainer:
                 raise NotImplementedError("chunked / compact-state updates are full-batch (num_mini_batch: 1)")
             if self.update_chunk_steps <= 0:   # rows are regenerated per chunk: keep them small; features are tiny
                 self.update_chunk_steps = buffer.episode_length if getattr(buffer, "structured", False) else 10
+            # No [rows, hidden] activation of a chunk may reach 2^31 elements: beyond that a torch kernel of the backward pass
+            # faults on this stack (hipErrorIllegalAddress at 9.8 M rows x 256 = the full c5 shard, 32 UAV x 2048 envs x 150
+            # steps; the library GEMMs themselves stay correct there, tools/big_rows_probe.py).  The chunked step is exact
+            # (gradient accumulation of a mean loss), so the batch is simply visited in more pieces.
+            rows_per_step = buffer.n_rollout_threads * buffer.num_agents
+            hidden = self.policy.actor.hidden_size
+            max_steps = max(1, (2 ** 31 - 1) // max(1, rows_per_step * hidden))
+            if self.update_chunk_steps > max_steps:
+                self.update_chunk_steps = max_steps
             if getattr(buffer, "structured", False):
                 # per-chunk state features: parameter-free, shared by all epochs, recomputed IN PLACE after a rollout
                 T, step = buffer.episode_length, max(1, int(self.update_chunk_steps))

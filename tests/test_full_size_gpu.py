@@ -145,3 +145,35 @@ def test_full_size_c3_iteration():
     assert torch.cuda.max_memory_allocated() / 1e9 < 20.0          # state-only buffer: ~18 GB peak (41 GB with dense rows)
     lr.train_envs.close()
     ptu.set_gpu_mode(False)
+
+
+def test_full_size_c5_shard_iteration():
+    """BASELINE configs[4]'s per-GPU shard through the learner: 32 UAV x 1024 PoI x 2048 envs x 150 steps with the pull
+    force on = 9,830,400 agent rows.  A [rows, 256] activation of the whole batch would have 2.5e9 elements; beyond 2^31
+    a torch kernel of the backward pass faults on this stack, so the trainer visits the batch in chunks that stay below it
+    (exact: gradient accumulation of a mean loss).  One rollout + one PPO epoch, finite and invariant checks."""
+    import yaml
+    from argparse import Namespace
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    torch.cuda.empty_cache()
+    from learner import Learner
+    cfg = {}
+    for f in ("config/env_config/dcc.yaml", "config/algo_config/mappo.yaml", "config/expt.yaml"):
+        cfg.update(yaml.safe_load(open(os.path.join(PKG, f))))
+    cfg.update(num_agents=32, num_pois=1024, n_rollout_threads=2048, n_eval_rollout_threads=0, ppo_epoch=1, save_model=False,
+               n_iters=1, comm_force_scale=0.5, r_comm=0.1)
+    lr = Learner(Namespace(**cfg))
+    r = lr.rollout(lr.rl_buffer, lr.train_envs)
+    b = lr.rl_buffer
+    assert bool(torch.isfinite(b.returns).all()) and float((b.value_preds - b.value_preds[:, :, :1]).abs().max()) == 0.0
+    info = lr.rl_update()
+    rows_per_step = 2048 * 32
+    assert lr.trainer.update_chunk_steps * rows_per_step * 256 < 2 ** 31 <= 150 * rows_per_step * 256
+    assert lr.trainer.update_chunk_steps == (2 ** 31 - 1) // (rows_per_step * 256) == 127
+    assert all(np.isfinite(v) for v in info.values()), info
+    assert 0.9 < info["ratio"] < 1.1 and info["critic_grad_norm"] > 0 and 0.0 <= r["coverage_rate"] <= 1.0
+    lr.train_envs.close()
+    del lr
+    torch.cuda.empty_cache()
+    ptu.set_gpu_mode(False)
