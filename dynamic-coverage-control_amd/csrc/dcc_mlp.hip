@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kBlock) void rollout_record_k(const float* __restri
 // One wave per env: G[e] is loaded once for its N agent rows and (backward) dG[e] is summed in registers.
 // Wh^T lives in LDS as Wt[k][c] (conflict-free float4 reads, shared by the block's waves).
 template <int VEC, int VPL>
-__device__ __forceinline__ void l1_row_z(const float* __restrict__ Wt, int H, int HD, float hv, float mean_in,
+__device__ __forceinline__ void l1_row_z(const float* __restrict__ Wt, int H, int HD, float hv, float hv2, float mean_in,
                                          float rstd_in, const float (&Gv)[VPL][VEC], const float (&sv)[VPL][VEC],
                                          const float (&cv)[VPL][VEC], const int (&cb)[VPL], const bool (&ok)[VPL],
                                          float (&zr)[VPL][VEC]) {
@@ -573,8 +573,10 @@ __device__ __forceinline__ void l1_row_z(const float* __restrict__ Wt, int H, in
     for (int v = 0; v < VPL; ++v)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) u[v][j] = 0.f;
+    // head value k of the row sits in lane k of hv (k < 64) or lane k - 64 of hv2 (up to 128 head columns: 63 UAVs)
     for (int k = 0; k < HD; ++k) {
-        const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), k));
+        const float x = k < 64 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), k))
+                               : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv2), k - 64));
 #pragma unroll
         for (int v = 0; v < VPL; ++v)
             if (ok[v]) {
@@ -627,10 +629,11 @@ __global__ __launch_bounds__(kBlock) void actor_l1_fwd_k(const float* __restrict
         if (ok[v]) { ld<VEC>(gamma + cb[v], g[v]); ld<VEC>(beta + cb[v], b[v]); ld<VEC>(s + cb[v], sv[v]); ld<VEC>(c + cb[v], cv[v]); }
     }
     const float invH = 1.0f / (float)H;
-    float nhv = 0.f;
+    float nhv = 0.f, nhv2 = 0.f;
     double nm = 0.0, nm2 = 0.0;
     auto fetch = [&](long long r) {
         nhv = lane < HD ? head[r * HD + lane] : 0.f;
+        nhv2 = lane + 64 < HD ? head[r * HD + 64 + lane] : 0.f;
         if (stats) { nm = stats[2 * r]; nm2 = stats[2 * r + 1]; }
     };
     if (gw < n) fetch(gw * N);
@@ -644,13 +647,13 @@ __global__ __launch_bounds__(kBlock) void actor_l1_fwd_k(const float* __restrict
         }
         for (int i = 0; i < N; ++i) {
             const long long r = e * N + i;
-            const float hv = nhv;
+            const float hv = nhv, hv2 = nhv2;
             float mean_in = 0.f, rstd_in = 1.f;
             if (stats) { mean_in = (float)nm; rstd_in = 1.0f / sqrtf((float)(nm2 * (1.0 / (double)D)) + eps_in); }
             const long long rn = (i + 1 < N) ? r + 1 : ((e + nw < n) ? (e + nw) * N : -1);
             if (rn >= 0) fetch(rn);     // the next row's head values / moments travel while this row is computed
             float a[VPL][VEC];
-            l1_row_z<VEC, VPL>(Wt, H, HD, hv, mean_in, rstd_in, Gv, sv, cv, cb, ok, a);
+            l1_row_z<VEC, VPL>(Wt, H, HD, hv, hv2, mean_in, rstd_in, Gv, sv, cv, cb, ok, a);
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
 #pragma unroll
@@ -939,9 +942,9 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
     const float invH = 1.0f / (float)H;
     // software pipeline, two rows deep: with ~100 accumulator registers per lane only two waves fit a SIMD, far too
     // few to hide HBM latency, so the loads of row t+2 (dh, head, input moments) are issued before row t is processed
-    float nd[2][VPL][VEC], nhv[2] = {0.f, 0.f};
+    float nd[2][VPL][VEC], nhv[2] = {0.f, 0.f}, nhw[2] = {0.f, 0.f};
     double nm[2] = {0.0, 0.0}, nm2[2] = {0.0, 0.0};
-    auto fetch = [&](long long r, float (&dd)[VPL][VEC], float& hv_, double& m_, double& m2_) {
+    auto fetch = [&](long long r, float (&dd)[VPL][VEC], float& hv_, float& hw_, double& m_, double& m2_) {
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
 #pragma unroll
@@ -949,19 +952,20 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
             if (ok[v]) ld<VEC>(dh + r * H + cb[v], dd[v]);
         }
         hv_ = lane < HD ? head[r * HD + lane] : 0.f;
+        hw_ = lane + 64 < HD ? head[r * HD + 64 + lane] : 0.f;
         if (stats) { m_ = stats[2 * r]; m2_ = stats[2 * r + 1]; }
     };
     // look-ahead cursor over this wave's row order (e, 0..N-1), (e + nw, 0..N-1), ...: (pe, pi) is the next row to fetch
     long long pe = gw;
     int pi = 0;
-    auto fetch_next = [&](float (&dd)[VPL][VEC], float& hv_, double& m_, double& m2_) {
+    auto fetch_next = [&](float (&dd)[VPL][VEC], float& hv_, float& hw_, double& m_, double& m2_) {
         if (pe < n) {
-            fetch(pe * N + pi, dd, hv_, m_, m2_);
+            fetch(pe * N + pi, dd, hv_, hw_, m_, m2_);
             if (++pi == N) { pi = 0; pe += nw; }
         }
     };
-    fetch_next(nd[0], nhv[0], nm[0], nm2[0]);
-    fetch_next(nd[1], nhv[1], nm[1], nm2[1]);
+    fetch_next(nd[0], nhv[0], nhw[0], nm[0], nm2[0]);
+    fetch_next(nd[1], nhv[1], nhw[1], nm[1], nm2[1]);
     for (long long e = gw; e < n; e += nw) {
         float Gv[VPL][VEC], dGv[VPL][VEC];
 #pragma unroll
@@ -977,13 +981,13 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
             for (int v = 0; v < VPL; ++v)
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) { d[v][j] = nd[0][v][j]; nd[0][v][j] = nd[1][v][j]; }
-            const float hv = nhv[0];
+            const float hv = nhv[0], hw = nhw[0];
             float mean_in = 0.f, rstd_in = 1.f;
             if (stats) { mean_in = (float)nm[0]; rstd_in = 1.0f / sqrtf((float)(nm2[0] * (1.0 / (double)D)) + eps_in); }
-            nhv[0] = nhv[1]; nm[0] = nm[1]; nm2[0] = nm2[1];
-            fetch_next(nd[1], nhv[1], nm[1], nm2[1]);   // row t+2 (row t+1 is already in flight)
+            nhv[0] = nhv[1]; nhw[0] = nhw[1]; nm[0] = nm[1]; nm2[0] = nm2[1];
+            fetch_next(nd[1], nhv[1], nhw[1], nm[1], nm2[1]);   // row t+2 (row t+1 is already in flight)
             float zr[VPL][VEC], a[VPL][VEC];
-            l1_row_z<VEC, VPL>(Wt, H, HD, hv, mean_in, rstd_in, Gv, sv, cv, cb, ok, zr);
+            l1_row_z<VEC, VPL>(Wt, H, HD, hv, hw, mean_in, rstd_in, Gv, sv, cv, cb, ok, zr);
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
 #pragma unroll
@@ -1071,11 +1075,20 @@ bool pick_shape(int H, Shape& sh) {
     if (H <= 128) { sh = {1, 2}; return true; }
     return false;
 }
+constexpr int kHdQOnly = 1000;   // 40 < HD <= 128: no in-register dWh accumulators, the backward stores q (dq != NULL)
+constexpr int kHdMax = 128;      // two head registers per lane: up to 63 UAVs
 int pad_hd(int HD) {
     if (HD <= 0) return 0;
     for (int p : {8, 16, 24, 40})
         if (HD <= p) return p;
-    return -1;
+    return HD <= kHdMax ? kHdQOnly : -1;
+}
+constexpr size_t kLdsMax = 160 * 1024;
+// Wh^T beyond 64 KB of LDS (HD > 64 at H = 256): raise the kernel's dynamic-LDS limit (160 KB per CU on gfx950)
+template <typename K>
+bool allow_lds(K kernel, size_t lds) {
+    return lds <= 64 * 1024 ||
+           hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
 }
 long long waves_for(long long units, int blocks) {
     long long b = (units + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -1133,8 +1146,10 @@ extern "C" {
 DCC_API int64_t dcc_mlp_workspace_floats(int32_t H, int32_t HD) {
     Shape sh;
     if (!pick_shape(H, sh)) return 0;
-    const int hdp = pad_hd(HD);
+    int hdp = pad_hd(HD);
     if (hdp < 0) return 0;
+    if (hdp == kHdQOnly) hdp = 0;
+    if ((size_t)HD * H * sizeof(float) > kLdsMax) return 0;
     const int64_t a = (int64_t)kReluLnBlocks * kWavesPerBlock * (3 + kAMax) * H;
     int64_t b = HD > 0 ? (int64_t)kL1Blocks * kWavesPerBlock * (hdp + 4) * H : 0;
     const int64_t b2 = HD > 0 ? (int64_t)kL1Blocks * 2 * kWavesPerBlock * 4 * H : 0;
@@ -1258,9 +1273,14 @@ DCC_API int dcc_actor_l1_fwd(const float* head, const float* G, const double* st
                              int32_t D, float* h, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
     if (!head || !G || !Wh || !s || !c || !gamma || !beta || !h || n < 1 || N < 1 || D < 1) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     Shape sh;
-    if (!pick_shape(H, sh) || HD < 0 || HD > 64 || pad_hd(HD) < 0) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (!pick_shape(H, sh) || HD < 0 || HD > kHdMax || pad_hd(HD) < 0) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
     const size_t lds = (size_t)HD * H * sizeof(float);
-    if (lds > 64 * 1024) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (lds > kLdsMax) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (lds > 64 * 1024) {
+        const bool okl = sh.vec == 4 ? (sh.vpl == 1 ? allow_lds(actor_l1_fwd_k<4, 1>, lds) : allow_lds(actor_l1_fwd_k<4, 2>, lds))
+                                     : (sh.vpl == 1 ? allow_lds(actor_l1_fwd_k<1, 1>, lds) : allow_lds(actor_l1_fwd_k<1, 2>, lds));
+        if (!okl) return dcc_fail(kEHIP, std::string(__func__) + ": could not raise the dynamic LDS limit");
+    }
     if (sh.vec == 4 && !(aligned16(G) && aligned16(h) && aligned16(gamma) && aligned16(beta) && aligned16(s) && aligned16(c)))
         return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
@@ -1293,9 +1313,15 @@ DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* st
         return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     Shape sh;
     const int hdp = pad_hd(HD);
-    if (!pick_shape(H, sh) || HD < 0 || HD > 64 || hdp < 0) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (!pick_shape(H, sh) || HD < 0 || HD > kHdMax || hdp < 0) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (hdp == kHdQOnly && !dq) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": more than 40 head columns need the q-storing form (dq != NULL)");
     const size_t lds = (size_t)HD * H * sizeof(float);
-    if (lds > 64 * 1024) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (lds > kLdsMax) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (lds > 64 * 1024) {
+        const bool okl = sh.vec == 4 ? (sh.vpl == 1 ? allow_lds(actor_l1_bwd_k<4, 1, 0>, lds) : allow_lds(actor_l1_bwd_k<4, 2, 0>, lds))
+                                     : (sh.vpl == 1 ? allow_lds(actor_l1_bwd_k<1, 1, 0>, lds) : allow_lds(actor_l1_bwd_k<1, 2, 0>, lds));
+        if (!okl) return dcc_fail(kEHIP, std::string(__func__) + ": could not raise the dynamic LDS limit");
+    }
     if (sh.vec == 4 && !(aligned16(G) && aligned16(dh) && aligned16(dG) && aligned16(gamma) && aligned16(s) &&
                          aligned16(c) && aligned16(workspace)))
         return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");

@@ -504,7 +504,7 @@ def actor_l1_bwd(head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, D, two_ker
         # (actor_l1_bwd_env_k<NR, true>: 2.85 ms at 4.9 M rows vs 3.97 ms for q + GEMM, and no [rows, H] scratch);
         # other shapes: the generic one-kernel form is register-starved, long batches store q and run a GEMM
         base_size = H == 256 and N in (4, 8) and HD == 4 + 2 * (N - 1)
-        two_kernel = (R >= 65536 and not base_size) or os.environ.get("DCC_L1_TWO_KERNEL") == "1"
+        two_kernel = (R >= 65536 and not base_size) or HD > 40 or os.environ.get("DCC_L1_TWO_KERNEL") == "1"
     dG = torch.empty_like(G)
     vecs = torch.empty((4, H), dtype=torch.float32, device=dev)     # ds, dc, dgamma, dbeta
     ws = torch.empty(L.dcc_mlp_workspace_floats(H, max(HD, 1)), dtype=torch.float32, device=dev)

@@ -108,7 +108,8 @@ DCC_API int dcc_rollout_record(const float* reward, const uint8_t* done, float* 
 
 /*
  * Actor first block from compact features of n env states with N agents each (rows r = e*N + i):
- *   head  [n,N,HD] f32, HD = 4 + 2(N-1)      dcc_obs_features
+ *   head  [n,N,HD] f32, HD = 4 + 2(N-1) <= 128 (two head registers per lane: up to 63 UAVs; Wh^T [HD,H] in LDS, <= 160 KB)
+ *                                            dcc_obs_features
  *   G     [n,H]    f32                       per-env term  poi_feat . [We;Wd]^T + const   (shared by the N agents)
  *   stats [n,N,2]  f64 or NULL               (mean, sum sq. dev.) of each observation row; NULL = no input LayerNorm
  *   Wh [H,HD], s [H] (row sums of the folded weight), c [H] (folded bias);  D = observation width, eps_in = input-LN eps
@@ -128,7 +129,7 @@ DCC_API int dcc_actor_l1_fwd(const float* head, const float* G, const double* st
  * dq != NULL ([n*N,H]): the kernel stores q = rstd_in * dL/dz there instead and leaves dWh untouched -- the caller
  * forms dWh = q^T head as a (split-K) GEMM; without the accumulators the kernel runs at full occupancy, which is
  * faster for long batches even with the extra [rows,H] write (2.7 vs 7.1 ms at 4.9 M rows).  HD = 0: dWh and dq may both be
- * NULL (dG is then the gradient of the per-env GEMM output). */
+ * NULL (dG is then the gradient of the per-env GEMM output).  HD > 40: only the q-storing form (dq != NULL). */
 DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
                              const float* c, const float* gamma, const float* dh, float eps_in, float eps_ln, int32_t D,
                              float* dG, float* dWh, float* dq, float* ds, float* dc, float* dgamma, float* dbeta,

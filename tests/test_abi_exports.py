@@ -84,9 +84,9 @@ def test_mlp_entry_points_validate_before_touching_the_device():
     """include/dcc_mlp.h: shape support query and argument validation run on the host (no GPU needed here)."""
     import dcc_hip
     L = dcc_hip.load_library()
-    assert L.dcc_mlp_workspace_floats(256, 18) >= L.dcc_mlp_workspace_floats(256, 0) > 0
+    assert L.dcc_mlp_workspace_floats(256, 18) >= L.dcc_mlp_workspace_floats(256, 0) > 0 and L.dcc_mlp_workspace_floats(256, 66) > 0
     assert L.dcc_mlp_workspace_floats(64, 10) > 0 and L.dcc_mlp_workspace_floats(512, 0) > 0
-    for H, HD in ((1000, 0), (130, 0), (0, 0), (256, 41), (516, 0)):
+    for H, HD in ((1000, 0), (130, 0), (0, 0), (256, 129), (512, 100), (516, 0)):     # (512, 100): Wh^T would need 200 KB of LDS
         assert L.dcc_mlp_workspace_floats(H, HD) == 0, (H, HD)
     buf = (ctypes.c_float * 64)()
     p = ctypes.cast(buf, ctypes.c_void_p)
@@ -96,7 +96,7 @@ def test_mlp_entry_points_validate_before_touching_the_device():
     assert L.dcc_relu_ln_bwd(p, None, p, p, 1e-5, p, p, None, 4, 8, None) == -1      # no workspace
     assert L.dcc_relu_ln_head_fwd(p, None, p, p, 1e-5, p, None, p, 4, 8, 5, None) == -4    # head wider than 4
     assert L.dcc_relu_ln_head_bwd(p, None, p, p, 1e-5, p, p, p, p, None, 4, 8, 2, None) == -1
-    assert L.dcc_actor_l1_fwd(p, p, None, p, p, p, p, p, 1e-5, 1e-5, 90, p, 1, 4, 70, 8, None) == -4   # head width > 64
+    assert L.dcc_actor_l1_fwd(p, p, None, p, p, p, p, p, 1e-5, 1e-5, 90, p, 1, 4, 130, 8, None) == -4   # head width > 128
     assert L.dcc_actor_l1_bwd(p, p, None, p, p, p, p, p, 1e-5, 1e-5, 90, p, None, None, p, p, p, p, p, 1, 4, 10, 8, None) == -1
     assert L.dcc_ppo_policy_loss(p, p, p, p, p, None, 0.2, p, p, p, 16, 5, 2, None) == -4   # more than 4 action dims
     assert L.dcc_ppo_policy_loss(p, p, p, p, p, None, 0.2, None, p, p, 16, 2, 2, None) == -1

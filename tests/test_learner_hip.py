@@ -320,15 +320,15 @@ def test_structured_input_trains_like_the_full_buffer():
 
 
 def test_structured_input_with_shapes_outside_the_fused_variants():
-    """20 UAVs -> 42 head columns (> the 40 the fused actor-L1 kernel is compiled for) and hidden width 72 (no float4
+    """64 UAVs -> 130 head columns (> the 128 the fused actor-L1 kernel reaches with two head registers) and hidden width 72 (no float4
     variant): the structured path must still run, on the unfused torch formulation of the same algebra."""
     import utils.pytorch_utils as ptu
     ptu.set_gpu_mode(True, 0)
     import dcc_hip
     from learner import Learner
-    assert not dcc_hip.mlp_fused_supported(64, 42) and dcc_hip.mlp_fused_supported(64, 0)
+    assert not dcc_hip.mlp_fused_supported(64, 130) and dcc_hip.mlp_fused_supported(64, 66) and dcc_hip.mlp_fused_supported(64, 0)
     for hidden in (64, 72):
-        lr = Learner(_cfg(n_rollout_threads=8, n_eval_rollout_threads=0, num_agents=20, num_pois=30, max_ep_len=6, n_iters=1,
+        lr = Learner(_cfg(n_rollout_threads=8, n_eval_rollout_threads=0, num_agents=64, num_pois=30, max_ep_len=6, n_iters=1,
                           ppo_epoch=2, algo_hidden_size=hidden, save_model=False, structured_input=True))
         r = lr.rollout(lr.rl_buffer, lr.train_envs)
         info = lr.rl_update()
@@ -341,7 +341,7 @@ def test_structured_input_with_shapes_outside_the_fused_variants():
             v_s = lr.policy.critic(feats)[0]
             v_d = lr.policy.critic(rows.reshape(8, -1))[0]
             a_s, _, _ = lr.policy.actor(feats, deterministic=True)
-            a_d, _, _ = lr.policy.actor(rows.reshape(8 * 20, -1), deterministic=True)
+            a_d, _, _ = lr.policy.actor(rows.reshape(8 * 64, -1), deterministic=True)
         np.testing.assert_allclose(v_s.cpu().numpy(), v_d.cpu().numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(a_s.cpu().numpy(), a_d.cpu().numpy(), rtol=1e-4, atol=1e-5)
     ptu.set_gpu_mode(False)

@@ -21,7 +21,7 @@ def _close_grad(a, b, name, n_act):
     O(1).  Small cases (no flip expected) are compared tightly; for the large ones no entry may be off by more than
     a few flips' worth."""
     scale = float(b.abs().max()) + 1e-20
-    tol = 2e-4 if n_act < 100000 else 3e-2
+    tol = 2e-4 if n_act < 50000 else 3e-2
     assert float((a - b).abs().max()) <= tol * scale, (name, float((a - b).abs().max()), scale)
 
 
@@ -79,7 +79,7 @@ def test_unsupported_width_falls_back_to_torch_ops():
 
 @pytest.mark.parametrize("feature_norm", [True, False])
 @pytest.mark.parametrize("N,M,H,n", [(8, 64, 256, 517), (4, 20, 64, 33), (1, 9, 32, 5), (5, 37, 128, 70), (16, 256, 256, 40),
-                                     (11, 30, 256, 19)])
+                                     (11, 30, 256, 19), (32, 100, 256, 23), (20, 30, 64, 9), (63, 40, 256, 6)])
 def test_actor_first_block_matches_torch(N, M, H, n, feature_norm):
     """fused actor L1 (from dcc_obs_features of random states) == the torch formulation of structured.actor_trunk's
     first block == LayerNorm(ReLU(Linear(LayerNorm(rows)))) on the rows dcc_obs_expand builds."""
@@ -137,7 +137,7 @@ def test_shapes_outside_the_compiled_variants_are_refused():
     import dcc_hip
     L = dcc_hip.load_library()
     assert L.dcc_mlp_workspace_floats(256, 18) > 0 and L.dcc_mlp_workspace_floats(256, 0) > 0
-    assert L.dcc_mlp_workspace_floats(1000, 0) == 0 and L.dcc_mlp_workspace_floats(256, 41) == 0
+    assert L.dcc_mlp_workspace_floats(1000, 0) == 0 and L.dcc_mlp_workspace_floats(256, 129) == 0
     z = torch.zeros(4, 1000, device="cuda")
     v = torch.zeros(1000, device="cuda")
     rc = L.dcc_relu_ln_fwd(z.data_ptr(), None, v.data_ptr(), v.data_ptr(), 1e-5, z.data_ptr(), 4, 1000, None)
