@@ -349,7 +349,7 @@ class MAPPOTrainer:
                 acc += self._epoch(buffer, advantages, update_actor)
             acc /= self.ppo_epoch
             for k, v in zip(("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"),
-                            acc.tolist()):
+                            self._global_metrics(acc).tolist()):
                 info[k] = v
             return info
         cached = None
@@ -373,10 +373,21 @@ class MAPPOTrainer:
                 acc += torch.stack([vl.detach().double(), pl.detach().double(), ent.detach().double(), agn.double(), cgn.double(),
                                     imp.detach().mean().double()])
         acc /= (self.ppo_epoch * self.num_mini_batch)
-        vals = acc.tolist()   # the only host sync of the update
+        vals = self._global_metrics(acc).tolist()   # the only host sync of the update
         for k, v in zip(("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"), vals):
             info[k] = v
         return info
+
+    @staticmethod
+    def _global_metrics(acc):
+        """Losses / entropy / ratio are means over the local env shard: averaged over the (equally sized) shards they are the
+        job-wide means every rank logs (the gradient norms are global already).  One 6-element all-reduce per train()."""
+        dist = _dist()
+        if dist is not None:
+            acc = acc.clone()
+            dist.all_reduce(acc)
+            acc /= dist.get_world_size()
+        return acc
 
     def prep_training(self):
         self.policy.actor.train(); self.policy.critic.train()

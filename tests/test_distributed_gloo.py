@@ -85,10 +85,8 @@ def test_two_rank_update_equals_single_process_full_batch():
         p.join(60)
         assert p.exitcode == 0
     for rank, info, sd, vmean in res:
-        for k in info1:
-            if k in ("policy_loss", "value_loss", "dist_entropy", "ratio"):
-                continue   # per-rank losses are means over the local shard; the gradients are what is global
-            np.testing.assert_allclose(info[k], info1[k], rtol=1e-4, err_msg=k)   # global grad norms
+        for k in info1:   # losses are all-reduced means over the equally sized shards, the gradient norms are global: every
+            np.testing.assert_allclose(info[k], info1[k], rtol=1e-4, atol=1e-6, err_msg=k)   # rank logs the full-batch numbers
         for k in ref:
             np.testing.assert_allclose(sd[k], ref[k].numpy(), rtol=2e-4, atol=2e-6, err_msg="rank%d %s" % (rank, k))
         np.testing.assert_allclose(vmean, tr.value_normalizer.running_mean.numpy(), rtol=1e-5)
