@@ -4,8 +4,8 @@
 // every load/store of a wavefront is one coalesced 256-byte transaction.  The recurrence runs in
 // float32 in the reference's exact operation order (buffer/shared_buffer.py:199-208 with the
 // torch float32 `v * sqrt(var) + mean` of utils/valuenorm.py:75 folded in), compiled with
-// -ffp-contract=off, so the result is bit-identical to the reference's numpy loop.  The loads of
-// step t-1 do not depend on the recurrence, so they are issued ahead of it (software prefetch).
+// -ffp-contract=off, so the result is bit-identical to the reference's numpy loop.  The loads do not
+// depend on the recurrence, so 16 steps of them are kept in flight ahead of it (software prefetch).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -16,12 +16,35 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void dcc_gae_kernel(const float* __restrict__ rewards,
-                                                      const float* __restrict__ vpred,
-                                                      const float* __restrict__ masks,
-                                                      const float* __restrict__ denorm, float gamma, float gl,
-                                                      float* __restrict__ returns, float* __restrict__ adv, int T,
-                                                      long long C) {
+// U steps of loads are in flight per lane while the previous U steps' recurrence runs: the loads do not depend on the
+// recurrence, so the kernel is bound by HBM bandwidth (20 B per step and column), not by one memory latency per step.
+constexpr int kGaeAhead = 16;
+constexpr int kGaeBlock = 64;   // one wavefront per workgroup: C/64 workgroups spread over all CUs at c3 (32,768 columns)
+
+struct GaeChunk {
+    float r[kGaeAhead], v[kGaeAhead], m[kGaeAhead];
+};
+
+// steps t0, t0-1, .., t0-U+1 of column c (steps below 0 are not read)
+__device__ __forceinline__ void gae_fetch(GaeChunk& q, const float* __restrict__ rewards, const float* __restrict__ vpred,
+                                          const float* __restrict__ masks, int t0, long long C, long long c) {
+#pragma unroll
+    for (int u = 0; u < kGaeAhead; ++u) {
+        const int t = t0 - u;
+        if (t >= 0) {
+            q.r[u] = rewards[(long long)t * C + c];
+            q.v[u] = vpred[(long long)t * C + c];
+            q.m[u] = masks[(long long)(t + 1) * C + c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kGaeBlock) void dcc_gae_kernel(const float* __restrict__ rewards,
+                                                            const float* __restrict__ vpred,
+                                                            const float* __restrict__ masks,
+                                                            const float* __restrict__ denorm, float gamma, float gl,
+                                                            float* __restrict__ returns, float* __restrict__ adv, int T,
+                                                            long long C) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float mean = 0.f, sd = 1.f;
@@ -31,27 +54,27 @@ __global__ __launch_bounds__(256) void dcc_gae_kernel(const float* __restrict__ 
     float v_next = vpred[(long long)T * C + c];
     if (dn) v_next = v_next * sd + mean;
     float gae = 0.f;
-    // prefetch step T-1
-    float r = rewards[(long long)(T - 1) * C + c];
-    float v = vpred[(long long)(T - 1) * C + c];
-    float m = masks[(long long)T * C + c];
-    for (int t = T - 1; t >= 0; --t) {
-        float r_p = 0.f, v_p = 0.f, m_p = 0.f;
-        if (t > 0) {
-            r_p = rewards[(long long)(t - 1) * C + c];
-            v_p = vpred[(long long)(t - 1) * C + c];
-            m_p = masks[(long long)t * C + c];
+    GaeChunk cur, nxt;
+    gae_fetch(cur, rewards, vpred, masks, T - 1, C, c);
+    for (int t0 = T - 1; t0 >= 0; t0 -= kGaeAhead) {
+        gae_fetch(nxt, rewards, vpred, masks, t0 - kGaeAhead, C, c);
+#pragma unroll
+        for (int u = 0; u < kGaeAhead; ++u) {
+            const int t = t0 - u;
+            if (t >= 0) {
+                const float r = cur.r[u], m = cur.m[u];
+                const float v_cur = dn ? (cur.v[u] * sd + mean) : cur.v[u];
+                // delta = r[t] + gamma * V[t+1] * mask[t+1] - V[t]          (shared_buffer.py:203-205)
+                const float delta = (r + (gamma * v_next) * m) - v_cur;
+                // gae = delta + gamma*lambda * mask[t+1] * gae               (shared_buffer.py:206)
+                gae = delta + (gl * m) * gae;
+                const float ret = gae + v_cur;                              // shared_buffer.py:207
+                returns[(long long)t * C + c] = ret;
+                if (adv) adv[(long long)t * C + c] = ret - v_cur;           // mappo.py:191
+                v_next = v_cur;
+            }
         }
-        const float v_cur = dn ? (v * sd + mean) : v;
-        // delta = r[t] + gamma * V[t+1] * mask[t+1] - V[t]          (shared_buffer.py:203-205)
-        const float delta = (r + (gamma * v_next) * m) - v_cur;
-        // gae = delta + gamma*lambda * mask[t+1] * gae               (shared_buffer.py:206)
-        gae = delta + (gl * m) * gae;
-        const float ret = gae + v_cur;                              // shared_buffer.py:207
-        returns[(long long)t * C + c] = ret;
-        if (adv) adv[(long long)t * C + c] = ret - v_cur;           // mappo.py:191
-        v_next = v_cur;
-        r = r_p; v = v_p; m = m_p;
+        cur = nxt;
     }
 }
 
@@ -64,7 +87,7 @@ DCC_API int dcc_gae_compute(const float* rewards, const float* value_preds, cons
                             void* stream) {
     if (!rewards || !value_preds || !masks || !returns) return dcc_fail(-1, "dcc_gae_compute: rewards / value_preds / masks / returns must not be NULL");
     if (T < 1 || C < 1) return dcc_fail(-1, "dcc_gae_compute: T and C must be >= 1");
-    const int block = 256;
+    const int block = kGaeBlock;
     const long long grid = (C + block - 1) / block;
     if (grid > 0x7fffffffLL) return dcc_fail(-1, "dcc_gae_compute: too many columns for one launch");
     // numpy turns the Python floats into float32 scalars: gamma -> f32(gamma), gamma*lambda (computed
