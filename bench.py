@@ -352,7 +352,6 @@ def main():
         return res
 
     import dcc_hip
-    from oracle import oracle  # only for generating the synthetic action stream + cpu_baseline leg
 
     E, N, M, T, L = args.envs, args.agents, args.pois, args.steps_per_launch, args.launches_per_step
     r_cover, crs, cfs, r_comm = 0.2, args.comm_r_scale, args.comm_force_scale, args.r_comm
@@ -367,7 +366,8 @@ def main():
         out = {k: v for k, v in out.items() if k in ("obs", "assign")}
     actions = None
     if args.actions == "hbm":
-        acts = np.stack([oracle.rng_actions(0, k, E, N, rank * E, world * E) for k in range(T)])
+        # synthetic action stream, a different one per rank (the oracle is only the cpu_baseline leg's business)
+        acts = np.random.default_rng(1000 + rank).uniform(-1.0, 1.0, (T, E, N, 2)).astype(np.float32)
         actions = torch.from_numpy(acts).to(dev)
 
     def run(n_steps, events=None):
