@@ -390,10 +390,14 @@ class Learner:
 
     # ---- headless evaluation ---------------------------------------------------------
     @torch.no_grad()
-    def evaluate(self, envs=None, steps=None, deterministic=True, dump_path=None):
+    def evaluate(self, envs=None, steps=None, deterministic=False, dump_path=None):
         """Roll the current policy without learning and report the metrics of the reference's README curves
         (coverage rate, steps needed to cover every PoI).  `dump_path` gets the trajectory (positions,
-        PoI energies, rewards, flags per step) as an .npz -- the headless stand-in for the pyglet viewer."""
+        PoI energies, rewards, flags per step) as an .npz -- the headless stand-in for the pyglet viewer.
+        Actions are SAMPLED by default, like the reference's test / render rollouts (learner.py:143-149 run the same
+        `collect` as training); deterministic=True plays the distribution's mean instead.  The two differ a lot for this
+        task: the policy trained for 1500 iterations on the shipped scenario covers every PoI in 44 steps when sampled
+        and stalls at half coverage on its mean (profiles/r02/training_run_1500_iters_and_shard_mappo.txt)."""
         envs = envs if envs is not None else (self.test_envs if self.test_envs is not None else self.train_envs)
         T = steps or self.max_ep_len
         E, N = envs.n_envs, self.n_agents
