@@ -129,7 +129,8 @@ class MAPPOTrainer:
         self._use_value_active_masks = cfg.use_value_active_masks
         self._use_policy_active_masks = cfg.use_policy_active_masks
         if cfg.use_popart:
-            raise NotImplementedError("PopArt is disabled in the reference config and not built")
+            raise NotImplementedError("use_popart: disabled in the reference config and not built (the reference's PopArt.update "
+                                      "raises TypeError on its first call, algo_utils/popart.py:60-63)")
         self._use_recurrent_policy = bool(cfg.use_recurrent_policy)
         self._use_naive_recurrent = bool(cfg.use_naive_recurrent_policy)
         self.data_chunk_length = int(getattr(cfg, "data_chunk_length", 10))
