@@ -27,9 +27,9 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kReluLnBlocks = 1024;   // 4096 waves: 16 per CU
 constexpr int kL1Blocks = 512;        // 2048 waves (the L1 backward keeps ~100 accumulators per lane)
 
-// Wave-wide sum, result in every lane.  Four DPP adds (VALU, no LDS round trip) leave each 16-lane row with its row
-// sum; the four row sums are combined through readlane.  (__shfl_xor compiles to ds_bpermute: six dependent LDS
-// round trips per reduction.)
+// Wave-wide sum, result in every lane (a scalar register).  Four DPP adds (VALU, no LDS round trip) leave each 16-lane
+// row with its row sum, two row-broadcast adds carry them into lane 63, one readlane makes it wave-uniform.
+// (__shfl_xor compiles to ds_bpermute: six dependent LDS round trips per reduction.)
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -42,7 +42,14 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
     v += dpp_mov<0x141>(v);   // row_half_mirror
     v += dpp_mov<0x140>(v);   // row_mirror
-    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+    // row_bcast:15 into rows 1 and 3 (r0+r1, r2+r3), row_bcast:31 into rows 2 and 3 (lane 63 = r0+r1+r2+r3); rows outside
+    // row_mask keep their value.  Written as instructions because the compiler's DPP combiner only fuses a masked
+    // float add when all rows are enabled (it emits mov 0 / mov_dpp / add otherwise); the s_nop are the two wait states a
+    // DPP (and the readlane that follows) needs after a VALU write of its source.
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return lane_bcast(v, 63);
 }
 
 template <int VEC>
@@ -708,6 +715,8 @@ __device__ __forceinline__ void fetch_env(const float* __restrict__ head, const 
     ld<4>(G + e * 256 + lane * 4, in.G);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));   // two adjacent columns: one v_pk_fma_f32 per pair
+
 __device__ __forceinline__ float readlane_f(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
@@ -730,24 +739,29 @@ __device__ __forceinline__ void row_stats_full(const float (&a)[4], float eps, f
 // the k-loop fully unrolled on compile-time readlanes.  The row loop itself stays rolled: unrolling it lets the scheduler
 // overlap rows and blows the register budget (measured: 256 VGPRs / 189 spills for the backward at 8 UAVs).
 template <int NR>
-__device__ __forceinline__ void env_row_z(const EnvIn<NR>& in, const int i, const int lane, const float (&w)[EnvIn<NR>::HD][4],
+__device__ __forceinline__ void env_row_z(const EnvIn<NR>& in, const int i, const int lane, const v2f (&w)[EnvIn<NR>::HD][2],
                                           const bool has_stats, float invD, float eps_in, const float (&sv)[4],
-                                          const float (&cv)[4], float (&zr)[4], float& mean_in, float& rstd_in, float& hv) {
+                                          const float (&cv)[4], float (&zr)[4], float& mean_in, float& rstd_in,
+                                          float (&xs)[EnvIn<NR>::HD]) {
     constexpr int HD = EnvIn<NR>::HD;
     const int f = i * HD + lane;
-    hv = __shfl(in.h[0], f & 63, 64);
+    float hv = __shfl(in.h[0], f & 63, 64);
 #pragma unroll
     for (int r = 1; r < EnvIn<NR>::HW; ++r) {
         const float t = __shfl(in.h[r], f & 63, 64);
         hv = (f >> 6) == r ? t : hv;
     }
-    float u[4] = {0.f, 0.f, 0.f, 0.f};
+    // the column pairs are explicit 2-vectors: left to itself the vectoriser pairs over k for part of the loop (a
+    // v_pk_mul + 2 adds per pair) and leaves the rest scalar -- 88 VALU instructions per row instead of 36
+    v2f u0 = {0.f, 0.f}, u1 = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < HD; ++k) {
-        const float x = readlane_f(hv, k);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) u[j] += x * w[k][j];
+        const float x = xs[k] = readlane_f(hv, k);   // wave-uniform (a scalar register); the backward reuses it
+        const v2f xx = {x, x};
+        u0 = xx * w[k][0] + u0;
+        u1 = xx * w[k][1] + u1;
     }
+    const float u[4] = {u0.x, u0.y, u1.x, u1.y};
     mean_in = 0.f; rstd_in = 1.f;
     if (has_stats) {
         mean_in = (float)readlane_d(in.st.x, i);
@@ -770,12 +784,14 @@ __global__ __launch_bounds__(kBlock, DCC_L1F_WAVES) void actor_l1_fwd_env_k(cons
     const long long gw = (long long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long nw = (long long)gridDim.x * kWavesPerBlock;
     const int cb = lane * 4;
-    float g[4], b[4], sv[4], cv[4], w[HD][4];
+    float g[4], b[4], sv[4], cv[4];
+    v2f w[HD][2];
     ld<4>(gamma + cb, g); ld<4>(beta + cb, b); ld<4>(s + cb, sv); ld<4>(c + cb, cv);
 #pragma unroll
-    for (int k = 0; k < HD; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[k][j] = Wh[(cb + j) * HD + k];
+    for (int k = 0; k < HD; ++k) {
+        w[k][0] = v2f{Wh[cb * HD + k], Wh[(cb + 1) * HD + k]};
+        w[k][1] = v2f{Wh[(cb + 2) * HD + k], Wh[(cb + 3) * HD + k]};
+    }
     const float invD = 1.0f / (float)D;
     const bool has_stats = stats != nullptr;
     EnvIn<NR> cur, nxt;
@@ -785,8 +801,8 @@ __global__ __launch_bounds__(kBlock, DCC_L1F_WAVES) void actor_l1_fwd_env_k(cons
         float* hrow = h + e * NR * H + cb;
 #pragma unroll 1
         for (int i = 0; i < NR; ++i) {
-            float a[4], mi, ri, hv;
-            env_row_z<NR>(cur, i, lane, w, has_stats, invD, eps_in, sv, cv, a, mi, ri, hv);
+            float a[4], mi, ri, xs[HD];
+            env_row_z<NR>(cur, i, lane, w, has_stats, invD, eps_in, sv, cv, a, mi, ri, xs);
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = fmaxf(a[j], 0.f);
             float mean, rstd;
@@ -815,16 +831,18 @@ __global__ __launch_bounds__(kBlock, DCC_L1B_WAVES) void actor_l1_bwd_env_k(cons
     const long long gw = (long long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long nw = (long long)gridDim.x * kWavesPerBlock;
     const int cb = lane * 4;
-    float g[4], sv[4], cv[4], w[HD][4];
+    float g[4], sv[4], cv[4];
+    v2f w[HD][2];
     float acc_g[4] = {0, 0, 0, 0}, acc_b[4] = {0, 0, 0, 0}, acc_s[4] = {0, 0, 0, 0}, acc_c[4] = {0, 0, 0, 0};
-    float aw[ACCW ? HD : 1][4];
+    v2f aw[ACCW ? HD : 1][2];
 #pragma unroll
-    for (int k = 0; k < (ACCW ? HD : 1); ++k) aw[k][0] = aw[k][1] = aw[k][2] = aw[k][3] = 0.f;
+    for (int k = 0; k < (ACCW ? HD : 1); ++k) aw[k][0] = aw[k][1] = v2f{0.f, 0.f};
     ld<4>(gamma + cb, g); ld<4>(s + cb, sv); ld<4>(c + cb, cv);
 #pragma unroll
-    for (int k = 0; k < HD; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[k][j] = Wh[(cb + j) * HD + k];
+    for (int k = 0; k < HD; ++k) {
+        w[k][0] = v2f{Wh[cb * HD + k], Wh[(cb + 1) * HD + k]};
+        w[k][1] = v2f{Wh[(cb + 2) * HD + k], Wh[(cb + 3) * HD + k]};
+    }
     const float invD = 1.0f / (float)D;
     const bool has_stats = stats != nullptr;
     // look-ahead cursor over this wave's dh rows: (pe, pi) is the next row to fetch
@@ -850,8 +868,8 @@ __global__ __launch_bounds__(kBlock, DCC_L1B_WAVES) void actor_l1_bwd_env_k(cons
 #pragma unroll
             for (int j = 0; j < 4; ++j) { d[j] = nd[0][j]; nd[0][j] = nd[1][j]; nd[1][j] = nd[2][j]; }
             fetch_dh(nd[2]);                                   // row t+3
-            float mean_in, rstd_in, hv;
-            env_row_z<NR>(cur, i, lane, w, has_stats, invD, eps_in, sv, cv, zr, mean_in, rstd_in, hv);
+            float mean_in, rstd_in, xs[HD];
+            env_row_z<NR>(cur, i, lane, w, has_stats, invD, eps_in, sv, cv, zr, mean_in, rstd_in, xs);
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = fmaxf(zr[j], 0.f);
             float mean, rstd;
@@ -878,11 +896,12 @@ __global__ __launch_bounds__(kBlock, DCC_L1B_WAVES) void actor_l1_bwd_env_k(cons
                 acc_c[j] += d[j];
             }
             if constexpr (ACCW) {
+                const v2f q0 = {q[0], q[1]}, q1 = {q[2], q[3]};
 #pragma unroll
                 for (int k = 0; k < HD; ++k) {
-                    const float x = readlane_f(hv, k);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) aw[k][j] += q[j] * x;
+                    const v2f xx = {xs[k], xs[k]};
+                    aw[k][0] = xx * q0 + aw[k][0];
+                    aw[k][1] = xx * q1 + aw[k][1];
                 }
             } else {
                 st<4>(qrow + (long long)i * H, q);
@@ -896,7 +915,10 @@ __global__ __launch_bounds__(kBlock, DCC_L1B_WAVES) void actor_l1_bwd_env_k(cons
     float* wv = ws + gw * (KW + 4) * H;
     if constexpr (ACCW) {
 #pragma unroll
-        for (int k = 0; k < HD; ++k) st<4>(wv + k * H + cb, aw[k]);
+        for (int k = 0; k < HD; ++k) {
+            const float t[4] = {aw[k][0].x, aw[k][0].y, aw[k][1].x, aw[k][1].y};
+            st<4>(wv + k * H + cb, t);
+        }
     }
     st<4>(wv + KW * H + cb, acc_s); st<4>(wv + (KW + 1) * H + cb, acc_c); st<4>(wv + (KW + 2) * H + cb, acc_g);
     st<4>(wv + (KW + 3) * H + cb, acc_b);
