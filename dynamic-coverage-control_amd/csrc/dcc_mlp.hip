@@ -683,9 +683,8 @@ __global__ __launch_bounds__(kBlock) void actor_l1_fwd_k(const float* __restrict
 // Two things bound the generic kernels above at 4.9 M rows: (1) Wh^T in LDS costs HD ds_read_b128 per lane and row (18 KB of
 // LDS reads per row at 8 UAVs: ~1.2 ms of pure LDS bandwidth per pass), (2) a row's inputs (72 B of head values, its moments)
 // are fetched one row ahead, which covers a fraction of the HBM latency at 4 waves per SIMD.  Here Wh^T lives in REGISTERS
-// (HD x 4 columns per lane), and everything an env's NR rows need -- the NR*HD head values as 1-3 coalesced loads, the NR
-// (mean, m2) pairs as one double2 load in lanes < NR, the G row -- is fetched a whole ENV ahead and broadcast per row with
-// compile-time readlanes.
+// (HD x 4 columns per lane), the env's G row is fetched a whole ENV ahead, and what the lanes of a row share (its HD head
+// values, its two moments) is read with SCALAR loads a row ahead into scalar registers.
 #ifndef DCC_L1F_WAVES
 #define DCC_L1F_WAVES 3     // waves per SIMD the env kernels are compiled for (register budget 512 / waves): at 4 the
 #endif                      // forward spills its prefetch registers to scratch, which serialises the HBM latency again
@@ -696,23 +695,44 @@ template <int NR>
 struct EnvIn {
     static constexpr int HD = 4 + 2 * (NR - 1);
     static constexpr int HW = (NR * HD + 63) / 64;
-    float h[HW];
-    double2 st;
+    float h[HW];     // the env's NR*HD head values, one coalesced load each: fetched only to pull their lines into L2
     float G[4];
 };
 
 template <int NR>
-__device__ __forceinline__ void fetch_env(const float* __restrict__ head, const double* __restrict__ stats,
-                                          const float* __restrict__ G, long long e, int lane, EnvIn<NR>& in) {
+__device__ __forceinline__ void fetch_env(const float* __restrict__ head, const float* __restrict__ G, long long e, int lane,
+                                          EnvIn<NR>& in) {
     constexpr int HD = EnvIn<NR>::HD;
 #pragma unroll
     for (int w = 0; w < EnvIn<NR>::HW; ++w) {
         const int idx = w * 64 + lane;
         in.h[w] = idx < NR * HD ? head[e * (NR * HD) + idx] : 0.f;
     }
-    in.st = make_double2(0.0, 0.0);
-    if (stats && lane < NR) in.st = reinterpret_cast<const double2*>(stats)[e * NR + lane];
     ld<4>(G + e * 256 + lane * 4, in.G);
+}
+template <int NR>
+__device__ __forceinline__ void keep_alive(const EnvIn<NR>& in) {
+#pragma unroll
+    for (int w = 0; w < EnvIn<NR>::HW; ++w) asm volatile("" ::"v"(in.h[w]));
+}
+
+// What a row's lanes share -- its HD head values and its input moments -- lives in SCALAR registers, loaded with scalar
+// loads (the addresses are wave-uniform) one row ahead: no gather, no readlane, and every multiply-add below takes its
+// multiplier straight from a scalar register.  A scalar load that misses L2 costs more than one row of work, which is why
+// fetch_env's vector loads still touch the env's head lines an env ahead.
+typedef const float __attribute__((address_space(4)))* cfloat_p;    // constant address space: selects s_load
+typedef const double __attribute__((address_space(4)))* cdouble_p;
+template <int HD>
+struct RowIn {
+    float x[HD];
+    double mean, m2;
+};
+template <int HD>
+__device__ __forceinline__ void fetch_row(cfloat_p head, cdouble_p stats, long long r, RowIn<HD>& o) {
+#pragma unroll
+    for (int k = 0; k < HD; ++k) o.x[k] = head[r * HD + k];
+    o.mean = 0.0; o.m2 = 0.0;
+    if (stats) { o.mean = stats[2 * r]; o.m2 = stats[2 * r + 1]; }
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));   // two adjacent columns: one v_pk_fma_f32 per pair
@@ -734,41 +754,31 @@ __device__ __forceinline__ void row_stats_full(const float (&a)[4], float eps, f
     rstd = fast_rsqrt(wave_sum(q) * (1.0f / 256.0f) + eps);
 }
 
-// Row i (runtime) of the env held in `in`: its HD head values gathered into ONE register (lane k <- head[i][k]) with one
-// ds_bpermute per held register, its input moments by readlane; then z = rstd_in * (head_i . Wh^T + G - mean_in s) + c with
-// the k-loop fully unrolled on compile-time readlanes.  The row loop itself stays rolled: unrolling it lets the scheduler
-// overlap rows and blows the register budget (measured: 256 VGPRs / 189 spills for the backward at 8 UAVs).
+// z = rstd_in * (head_row . Wh^T + G - mean_in s) + c of one row, the k-loop fully unrolled on scalar multipliers.  The
+// row loop itself stays rolled: unrolling it lets the scheduler overlap rows and blows the register budget (measured: 256
+// VGPRs / 189 spills for the backward at 8 UAVs).
 template <int NR>
-__device__ __forceinline__ void env_row_z(const EnvIn<NR>& in, const int i, const int lane, const v2f (&w)[EnvIn<NR>::HD][2],
+__device__ __forceinline__ void env_row_z(const RowIn<EnvIn<NR>::HD>& row, const float (&Gv)[4], const v2f (&w)[EnvIn<NR>::HD][2],
                                           const bool has_stats, float invD, float eps_in, const float (&sv)[4],
-                                          const float (&cv)[4], float (&zr)[4], float& mean_in, float& rstd_in,
-                                          float (&xs)[EnvIn<NR>::HD]) {
+                                          const float (&cv)[4], float (&zr)[4], float& mean_in, float& rstd_in) {
     constexpr int HD = EnvIn<NR>::HD;
-    const int f = i * HD + lane;
-    float hv = __shfl(in.h[0], f & 63, 64);
-#pragma unroll
-    for (int r = 1; r < EnvIn<NR>::HW; ++r) {
-        const float t = __shfl(in.h[r], f & 63, 64);
-        hv = (f >> 6) == r ? t : hv;
-    }
     // the column pairs are explicit 2-vectors: left to itself the vectoriser pairs over k for part of the loop (a
     // v_pk_mul + 2 adds per pair) and leaves the rest scalar -- 88 VALU instructions per row instead of 36
     v2f u0 = {0.f, 0.f}, u1 = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < HD; ++k) {
-        const float x = xs[k] = readlane_f(hv, k);   // wave-uniform (a scalar register); the backward reuses it
-        const v2f xx = {x, x};
+        const v2f xx = {row.x[k], row.x[k]};
         u0 = xx * w[k][0] + u0;
         u1 = xx * w[k][1] + u1;
     }
     const float u[4] = {u0.x, u0.y, u1.x, u1.y};
     mean_in = 0.f; rstd_in = 1.f;
     if (has_stats) {
-        mean_in = (float)readlane_d(in.st.x, i);
-        rstd_in = fast_rsqrt((float)readlane_d(in.st.y, i) * invD + eps_in);
+        mean_in = (float)row.mean;
+        rstd_in = fast_rsqrt((float)row.m2 * invD + eps_in);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) zr[j] = rstd_in * (u[j] + in.G[j] - mean_in * sv[j]) + cv[j];
+    for (int j = 0; j < 4; ++j) zr[j] = rstd_in * (u[j] + Gv[j] - mean_in * sv[j]) + cv[j];
 }
 
 // H == 256 (every lane owns 4 valid columns: no predication anywhere in the row loop)
@@ -794,15 +804,21 @@ __global__ __launch_bounds__(kBlock, DCC_L1F_WAVES) void actor_l1_fwd_env_k(cons
     }
     const float invD = 1.0f / (float)D;
     const bool has_stats = stats != nullptr;
+    const cfloat_p head_s = (cfloat_p)head;
+    const cdouble_p stats_s = (cdouble_p)stats;
     EnvIn<NR> cur, nxt;
-    if (gw < n) fetch_env<NR>(head, stats, G, gw, lane, cur);
+    RowIn<HD> row, rown;
+    if (gw < n) { fetch_env<NR>(head, G, gw, lane, cur); fetch_row<HD>(head_s, stats_s, gw * NR, row); }
     for (long long e = gw; e < n; e += nw) {
-        if (e + nw < n) fetch_env<NR>(head, stats, G, e + nw, lane, nxt);   // a whole env ahead
+        const bool more = e + nw < n;
+        if (more) fetch_env<NR>(head, G, e + nw, lane, nxt);   // a whole env ahead
         float* hrow = h + e * NR * H + cb;
 #pragma unroll 1
         for (int i = 0; i < NR; ++i) {
-            float a[4], mi, ri, xs[HD];
-            env_row_z<NR>(cur, i, lane, w, has_stats, invD, eps_in, sv, cv, a, mi, ri, xs);
+            // the next row of this wave: the env's next agent, or the first agent of the wave's next env
+            fetch_row<HD>(head_s, stats_s, i + 1 < NR ? e * NR + i + 1 : (more ? e + nw : e) * NR, rown);
+            float a[4], mi, ri;
+            env_row_z<NR>(row, cur.G, w, has_stats, invD, eps_in, sv, cv, a, mi, ri);
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = fmaxf(a[j], 0.f);
             float mean, rstd;
@@ -811,7 +827,9 @@ __global__ __launch_bounds__(kBlock, DCC_L1F_WAVES) void actor_l1_fwd_env_k(cons
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (a[j] - mean) * rstd * g[j] + b[j];
             st<4>(hrow + (long long)i * H, o);
+            row = rown;
         }
+        keep_alive<NR>(cur);
         cur = nxt;
     }
 }
@@ -856,10 +874,14 @@ __global__ __launch_bounds__(kBlock, DCC_L1B_WAVES) void actor_l1_bwd_env_k(cons
     };
     float nd[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     fetch_dh(nd[0]); fetch_dh(nd[1]); fetch_dh(nd[2]);
+    const cfloat_p head_s = (cfloat_p)head;
+    const cdouble_p stats_s = (cdouble_p)stats;
     EnvIn<NR> cur, nxt;
-    if (gw < n) fetch_env<NR>(head, stats, G, gw, lane, cur);
+    RowIn<HD> row, rown;
+    if (gw < n) { fetch_env<NR>(head, G, gw, lane, cur); fetch_row<HD>(head_s, stats_s, gw * NR, row); }
     for (long long e = gw; e < n; e += nw) {
-        if (e + nw < n) fetch_env<NR>(head, stats, G, e + nw, lane, nxt);
+        const bool more = e + nw < n;
+        if (more) fetch_env<NR>(head, G, e + nw, lane, nxt);
         float dGv[4] = {0.f, 0.f, 0.f, 0.f};
         float* qrow = ACCW ? nullptr : dq + e * NR * H + cb;
 #pragma unroll 1
@@ -868,8 +890,9 @@ __global__ __launch_bounds__(kBlock, DCC_L1B_WAVES) void actor_l1_bwd_env_k(cons
 #pragma unroll
             for (int j = 0; j < 4; ++j) { d[j] = nd[0][j]; nd[0][j] = nd[1][j]; nd[1][j] = nd[2][j]; }
             fetch_dh(nd[2]);                                   // row t+3
-            float mean_in, rstd_in, xs[HD];
-            env_row_z<NR>(cur, i, lane, w, has_stats, invD, eps_in, sv, cv, zr, mean_in, rstd_in, xs);
+            fetch_row<HD>(head_s, stats_s, i + 1 < NR ? e * NR + i + 1 : (more ? e + nw : e) * NR, rown);
+            float mean_in, rstd_in;
+            env_row_z<NR>(row, cur.G, w, has_stats, invD, eps_in, sv, cv, zr, mean_in, rstd_in);
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = fmaxf(zr[j], 0.f);
             float mean, rstd;
@@ -899,15 +922,17 @@ __global__ __launch_bounds__(kBlock, DCC_L1B_WAVES) void actor_l1_bwd_env_k(cons
                 const v2f q0 = {q[0], q[1]}, q1 = {q[2], q[3]};
 #pragma unroll
                 for (int k = 0; k < HD; ++k) {
-                    const v2f xx = {xs[k], xs[k]};
+                    const v2f xx = {row.x[k], row.x[k]};
                     aw[k][0] = xx * q0 + aw[k][0];
                     aw[k][1] = xx * q1 + aw[k][1];
                 }
             } else {
                 st<4>(qrow + (long long)i * H, q);
             }
+            row = rown;
         }
         st<4>(dG + e * H + cb, dGv);
+        keep_alive<NR>(cur);
         cur = nxt;
     }
     // per-wave partials in l1_reduce_k's layout: [dWt rows (HD x H, ACCW only) | ds | dc | dgamma | dbeta]
