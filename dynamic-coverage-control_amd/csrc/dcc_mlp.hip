@@ -254,17 +254,23 @@ __global__ __launch_bounds__(kBlock) void relu_ln_head_fwd_k(const float* __rest
     float bias = 0.f;
     if (lane < A) bias = bo ? bo[lane] : 0.f;
     const float invH = 1.0f / (float)H;
+    // the only traffic is the z row (1 KB per wave and row) and the chain of reductions below is long: with the load
+    // issued where it is needed the kernel holds ~4 MB in flight, short of what HBM latency x bandwidth asks for, so the
+    // next row of the wave is fetched before this one is reduced
+    float nx[VPL][VEC];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) nx[v][j] = 0.f;
+        if (ok[v] && gw < R) ld<VEC>(z + gw * H + cb[v], nx[v]);
+    }
     for (long long r = gw; r < R; r += nw) {
         float a[VPL][VEC];
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) a[v][j] = 0.f;
-            if (ok[v]) {
-                ld<VEC>(z + r * H + cb[v], a[v]);
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) a[v][j] = fmaxf(a[v][j] + zb[v][j], 0.f);
-            }
+            for (int j = 0; j < VEC; ++j) a[v][j] = ok[v] ? fmaxf(nx[v][j] + zb[v][j], 0.f) : 0.f;
+            if (ok[v] && r + nw < R) ld<VEC>(z + (r + nw) * H + cb[v], nx[v]);
         }
         float mean, rstd;
         row_stats<VEC, VPL>(a, ok, invH, eps, mean, rstd);
@@ -319,20 +325,27 @@ __global__ __launch_bounds__(kBlock) void relu_ln_head_bwd_k(const float* __rest
         }
     }
     const float invH = 1.0f / (float)H;
+    // the wave's next row (z and its dy) is fetched before this one is processed, as in the forward
+    float nx[VPL][VEC], ndy[kAMax];
+#pragma unroll
+    for (int o = 0; o < kAMax; ++o) ndy[o] = (o < A && gw < R) ? dy[gw * A + o] : 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) nx[v][j] = 0.f;
+        if (ok[v] && gw < R) ld<VEC>(z + gw * H + cb[v], nx[v]);
+    }
     for (long long r = gw; r < R; r += nw) {
         float zr[VPL][VEC], a[VPL][VEC], d[VPL][VEC];
         float dyr[kAMax];
+        const bool more = r + nw < R;
 #pragma unroll
-        for (int o = 0; o < kAMax; ++o) dyr[o] = o < A ? dy[r * A + o] : 0.f;
+        for (int o = 0; o < kAMax; ++o) { dyr[o] = ndy[o]; if (o < A && more) ndy[o] = dy[(r + nw) * A + o]; }
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) zr[v][j] = 0.f;
-            if (ok[v]) {
-                ld<VEC>(z + r * H + cb[v], zr[v]);
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) zr[v][j] += zb[v][j];
-            }
+            for (int j = 0; j < VEC; ++j) zr[v][j] = ok[v] ? nx[v][j] + zb[v][j] : 0.f;
+            if (ok[v] && more) ld<VEC>(z + (r + nw) * H + cb[v], nx[v]);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) a[v][j] = fmaxf(zr[v][j], 0.f);
         }
