@@ -180,6 +180,7 @@ def mappo_iterations(args, iters, warm_iters=2):
            "iters_warmup": warm_iters, "s_per_iter": dt / iters, "rollout_s_per_iter": tr / iters,
            "update_s_per_iter": tu / iters, "rollout_agent_env_steps_per_sec": world * E * N * T / (tr / iters),
            "hip_graph_rollout": not args.no_graph, "rows_stored": bool(args.keep_rows), "structured_input": structured,
+           "tuned_gemm_entries": lr.tuned_gemms,
            "grad_allreduce": ("%s x%d" % ({"nccl": "rccl"}.get(dist.get_backend(), dist.get_backend()), world)) if world > 1 else "none (1 GPU)",
            "mlp_tflop_per_iter_reference_formulation": ref_fwd * rows * (1 + 3 * args.ppo_epoch) / 1e12,
            "mlp_tflop_per_iter_as_evaluated": ours_fwd * rows * (1 + 3 * args.ppo_epoch) / 1e12,

@@ -53,6 +53,8 @@ class Learner:
             self.cfg.structured_input = self.cfg.compact_obs = False
         self.rank, self.world = ptu.init_distributed() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
         utl.seed(self.cfg.seed + self.rank)
+        # measured-fastest library GEMM per listed shape instead of the library heuristic's pick (lookup only)
+        self.tuned_gemms = ptu.use_tuned_gemms() if getattr(self.cfg, "tuned_gemms", True) else 0
 
         # 1. env (global n_rollout_threads is sharded over ranks inside make_env)
         self.train_envs = make_env(cfg=copy.deepcopy(self.cfg))

@@ -30,6 +30,35 @@ def gpu_enabled():
     return _use_gpu
 
 
+TUNED_GEMMS_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "gemm_tunings_gfx950.csv")
+_tuned_gemms = None
+
+
+def use_tuned_gemms(path=None):
+    """Library-GEMM selection for the policy MLPs: the plain fp32 GEMMs stay rocBLAS / hipBLASLt calls issued by torch, and
+    for the shapes listed in config/gemm_tunings_gfx950.csv (the BASELINE sizes, produced by tools/tune_gemms.sh on an
+    MI355X) torch's TunableOp dispatches the solution that measured fastest instead of the library heuristic's pick
+    (c3: update GEMMs 5.0 -> 4.6-4.7 ms, +3.8 % per iteration).  LOOKUP ONLY -- nothing is tuned at run time, a shape that is
+    not listed takes the default path, and torch ignores the file when its validators (torch / ROCm / rocBLAS / hipBLASLt
+    versions, GPU arch) differ from this installation.  Returns the number of entries in use (0: default GEMMs).
+    DCC_TUNED_GEMMS=0 or a user-managed PYTORCH_TUNABLEOP_ENABLED leave everything as it is."""
+    global _tuned_gemms
+    if _tuned_gemms is not None and path is None:
+        return _tuned_gemms
+    n = 0
+    if (_use_gpu and os.environ.get("DCC_TUNED_GEMMS", "1") != "0" and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ
+            and os.path.exists(path or TUNED_GEMMS_FILE)):
+        import torch.cuda.tunable as tun
+        tun.enable(True)
+        tun.tuning_enable(False)
+        if tun.read_file(path or TUNED_GEMMS_FILE):
+            n = len(tun.get_results())
+        else:
+            tun.enable(False)
+    _tuned_gemms = n
+    return n
+
+
 def init_distributed(backend=None):
     """One process per GPU.  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment
     (torch.distributed.run); no-op when WORLD_SIZE is 1.  Returns (rank, world_size)."""
