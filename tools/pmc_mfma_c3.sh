@@ -53,6 +53,6 @@ for gui, k, n, util, sq, tf, ms in rows[:28]:
 gemm = [r for r in rows if r[1].startswith('Cijk')]
 g_busy = sum(acc[r[1]]['SQ_VALU_MFMA_BUSY_CYCLES'] for r in gemm); g_gui = sum(r[0] for r in gemm)
 all_busy = sum(d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) for d in acc.values())
-print("all hipBLASLt GEMMs: MFMA pipes busy %.3f of their GPU-active time; whole iteration: %.3f (GEMMs are %.1f%% of GPU-active cycles)"
+print("all library GEMMs (Cijk_*): MFMA pipes busy %.3f of their GPU-active time; whole iteration: %.3f (GEMMs are %.1f%% of GPU-active cycles)"
       % (g_busy / (g_gui / 8 * 1024), all_busy / (tot_gui / 8 * 1024), 100 * g_gui / tot_gui))
 PY

@@ -80,6 +80,8 @@ for V in "default:" "rows_stored:--keep-rows" "dense_rows:--no-structured-input"
   NAME=${V%%:*}; FLAGS=${V#*:}
   python bench.py --mode mappo --iters 3 $FLAGS 2>/dev/null | tail -1 > $OUT/mappo_c3_$NAME.json
 done
+DCC_TUNED_GEMMS=0 python bench.py --mode mappo --iters 3 2>/dev/null | tail -1 > $OUT/mappo_c3_untuned_gemms.json
+python tools/gae_time.py > $OUT/gae_kernel.txt 2>/dev/null
 tools/profile_mappo.sh r02_mappo_default > $OUT/mappo_c3_default_top_kernels.txt 2>&1
 cp gpurun_out/prof_r02_mappo_default/kernel_stats.csv $OUT/mappo_c3_default_kernel_stats.csv
 tools/profile_update_only.sh > $OUT/mappo_c3_update_only.txt 2>&1
