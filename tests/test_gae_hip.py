@@ -29,7 +29,8 @@ def test_gae_matches_reference_golden_bit_exact():
     np.testing.assert_array_equal(adv.cpu().numpy().reshape(T, E, N, 1), Z["adv_raw"])
 
 
-@pytest.mark.parametrize("T,C,use_vn", [(150, 4096 * 8, True), (150, 1000, False), (7, 33, True), (1, 1, True)])
+@pytest.mark.parametrize("T,C,use_vn", [(150, 4096 * 8, True), (150, 1000, False), (7, 33, True), (1, 1, True),
+                                          (16, 64, True), (17, 65, False), (32, 100, True), (33, 7, True), (400, 129, True)])   # around the 16-step look-ahead
 def test_gae_matches_oracle_random(T, C, use_vn):
     import dcc_hip
     from oracle import mappo_oracle as mo
