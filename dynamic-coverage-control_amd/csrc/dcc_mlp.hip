@@ -750,14 +750,6 @@ __device__ __forceinline__ void fetch_row(cfloat_p head, cdouble_p stats, long l
 
 typedef float v2f __attribute__((ext_vector_type(2)));   // two adjacent columns: one v_pk_fma_f32 per pair
 
-__device__ __forceinline__ float readlane_f(float v, int l) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-__device__ __forceinline__ double readlane_d(double v, int l) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
 // ReLU + LayerNorm moments of one full row of 256 (float4 per lane, every lane valid)
 __device__ __forceinline__ void row_stats_full(const float (&a)[4], float eps, float& mean, float& rstd) {
     mean = wave_sum((a[0] + a[1]) + (a[2] + a[3])) * (1.0f / 256.0f);
