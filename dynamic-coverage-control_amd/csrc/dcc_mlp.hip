@@ -583,16 +583,19 @@ __global__ __launch_bounds__(kBlock) void rollout_record_k(const float* __restri
 // z[r,c] = rstd_in[r] * (sum_k head[r,k] Wh[c,k] + G[e,c] - mean_in[r] s[c]) + cb[c];   h = LayerNorm(ReLU(z))
 // One wave per env: G[e] is loaded once for its N agent rows and (backward) dG[e] is summed in registers.
 // Wh^T lives in LDS as Wt[k][c] (conflict-free float4 reads, shared by the block's waves).
+// With many UAVs (HD = 34 at 16, 66 at 32) those HD LDS reads per lane and row bound the kernel (4.2 ms for 2.5 M rows at 16
+// UAVs where the 8-UAV register kernel needs 1.4 ms for 4.9 M), so the same kernels also take the per-row term READY-MADE:
+// pre[r,c] = sum_k head[r,k] Wh[c,k] from a library GEMM (Zp != NULL, HD = 0; dcc_actor_l1_pre_fwd / _bwd).
 template <int VEC, int VPL>
 __device__ __forceinline__ void l1_row_z(const float* __restrict__ Wt, int H, int HD, float hv, float hv2, float mean_in,
                                          float rstd_in, const float (&Gv)[VPL][VEC], const float (&sv)[VPL][VEC],
                                          const float (&cv)[VPL][VEC], const int (&cb)[VPL], const bool (&ok)[VPL],
-                                         float (&zr)[VPL][VEC]) {
+                                         const float (&u0)[VPL][VEC], float (&zr)[VPL][VEC]) {
     float u[VPL][VEC];
 #pragma unroll
     for (int v = 0; v < VPL; ++v)
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) u[v][j] = 0.f;
+        for (int j = 0; j < VEC; ++j) u[v][j] = u0[v][j];
     // head value k of the row sits in lane k of hv (k < 64) or lane k - 64 of hv2 (up to 128 head columns: 63 UAVs)
     for (int k = 0; k < HD; ++k) {
         const float x = k < 64 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), k))
@@ -624,8 +627,8 @@ __device__ __forceinline__ void in_stats(const double* __restrict__ stats, long 
 }
 
 template <int VEC, int VPL>
-__global__ __launch_bounds__(kBlock) void actor_l1_fwd_k(const float* __restrict__ head, const float* __restrict__ G,
-                                                         const double* __restrict__ stats,
+__global__ __launch_bounds__(kBlock) void actor_l1_fwd_k(const float* __restrict__ head, const float* __restrict__ Zp,
+                                                         const float* __restrict__ G, const double* __restrict__ stats,
                                                          const float* __restrict__ Wh, const float* __restrict__ s,
                                                          const float* __restrict__ c, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps_in, float eps_ln,
@@ -649,12 +652,21 @@ __global__ __launch_bounds__(kBlock) void actor_l1_fwd_k(const float* __restrict
         if (ok[v]) { ld<VEC>(gamma + cb[v], g[v]); ld<VEC>(beta + cb[v], b[v]); ld<VEC>(s + cb[v], sv[v]); ld<VEC>(c + cb[v], cv[v]); }
     }
     const float invH = 1.0f / (float)H;
-    float nhv = 0.f, nhv2 = 0.f;
+    float nhv = 0.f, nhv2 = 0.f, nz[VPL][VEC];
     double nm = 0.0, nm2 = 0.0;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) nz[v][j] = 0.f;
     auto fetch = [&](long long r) {
         nhv = lane < HD ? head[r * HD + lane] : 0.f;
         nhv2 = lane + 64 < HD ? head[r * HD + 64 + lane] : 0.f;
         if (stats) { nm = stats[2 * r]; nm2 = stats[2 * r + 1]; }
+        if (Zp) {
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+                if (ok[v]) ld<VEC>(Zp + r * H + cb[v], nz[v]);
+        }
     };
     if (gw < n) fetch(gw * N);
     for (long long e = gw; e < n; e += nw) {
@@ -668,12 +680,16 @@ __global__ __launch_bounds__(kBlock) void actor_l1_fwd_k(const float* __restrict
         for (int i = 0; i < N; ++i) {
             const long long r = e * N + i;
             const float hv = nhv, hv2 = nhv2;
-            float mean_in = 0.f, rstd_in = 1.f;
+            float mean_in = 0.f, rstd_in = 1.f, u0[VPL][VEC];
             if (stats) { mean_in = (float)nm; rstd_in = 1.0f / sqrtf((float)(nm2 * (1.0 / (double)D)) + eps_in); }
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) u0[v][j] = nz[v][j];
             const long long rn = (i + 1 < N) ? r + 1 : ((e + nw < n) ? (e + nw) * N : -1);
-            if (rn >= 0) fetch(rn);     // the next row's head values / moments travel while this row is computed
+            if (rn >= 0) fetch(rn);     // the next row's head values / moments / ready-made term travel while this row is computed
             float a[VPL][VEC];
-            l1_row_z<VEC, VPL>(Wt, H, HD, hv, hv2, mean_in, rstd_in, Gv, sv, cv, cb, ok, a);
+            l1_row_z<VEC, VPL>(Wt, H, HD, hv, hv2, mean_in, rstd_in, Gv, sv, cv, cb, ok, u0, a);
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
 #pragma unroll
@@ -957,8 +973,8 @@ __global__ __launch_bounds__(kBlock, DCC_L1B_WAVES) void actor_l1_bwd_env_k(cons
 // per-wave partial vector of the L1 backward: [dWt (HDP*H) | ds (H) | dc (H) | dgamma (H) | dbeta (H)].
 // HDP = 0: no dWh accumulators (they are what limits the kernel to 2 waves/SIMD); q = rstd_in * dz is stored instead.
 template <int VEC, int VPL, int HDP>
-__global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict__ head, const float* __restrict__ G,
-                                                         const double* __restrict__ stats,
+__global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict__ head, const float* __restrict__ Zp,
+                                                         const float* __restrict__ G, const double* __restrict__ stats,
                                                          const float* __restrict__ Wh, const float* __restrict__ s,
                                                          const float* __restrict__ c, const float* __restrict__ gamma,
                                                          const float* __restrict__ dh, float eps_in, float eps_ln,
@@ -994,14 +1010,20 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
     const float invH = 1.0f / (float)H;
     // software pipeline, two rows deep: with ~100 accumulator registers per lane only two waves fit a SIMD, far too
     // few to hide HBM latency, so the loads of row t+2 (dh, head, input moments) are issued before row t is processed
-    float nd[2][VPL][VEC], nhv[2] = {0.f, 0.f}, nhw[2] = {0.f, 0.f};
+    float nd[2][VPL][VEC], nz[2][VPL][VEC], nhv[2] = {0.f, 0.f}, nhw[2] = {0.f, 0.f};
     double nm[2] = {0.0, 0.0}, nm2[2] = {0.0, 0.0};
-    auto fetch = [&](long long r, float (&dd)[VPL][VEC], float& hv_, float& hw_, double& m_, double& m2_) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) nz[t][v][j] = 0.f;
+    auto fetch = [&](long long r, float (&dd)[VPL][VEC], float (&zz)[VPL][VEC], float& hv_, float& hw_, double& m_, double& m2_) {
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) dd[v][j] = 0.f;
-            if (ok[v]) ld<VEC>(dh + r * H + cb[v], dd[v]);
+            if (ok[v]) { ld<VEC>(dh + r * H + cb[v], dd[v]); if (Zp) ld<VEC>(Zp + r * H + cb[v], zz[v]); }
         }
         hv_ = lane < HD ? head[r * HD + lane] : 0.f;
         hw_ = lane + 64 < HD ? head[r * HD + 64 + lane] : 0.f;
@@ -1010,14 +1032,14 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
     // look-ahead cursor over this wave's row order (e, 0..N-1), (e + nw, 0..N-1), ...: (pe, pi) is the next row to fetch
     long long pe = gw;
     int pi = 0;
-    auto fetch_next = [&](float (&dd)[VPL][VEC], float& hv_, float& hw_, double& m_, double& m2_) {
+    auto fetch_next = [&](float (&dd)[VPL][VEC], float (&zz)[VPL][VEC], float& hv_, float& hw_, double& m_, double& m2_) {
         if (pe < n) {
-            fetch(pe * N + pi, dd, hv_, hw_, m_, m2_);
+            fetch(pe * N + pi, dd, zz, hv_, hw_, m_, m2_);
             if (++pi == N) { pi = 0; pe += nw; }
         }
     };
-    fetch_next(nd[0], nhv[0], nhw[0], nm[0], nm2[0]);
-    fetch_next(nd[1], nhv[1], nhw[1], nm[1], nm2[1]);
+    fetch_next(nd[0], nz[0], nhv[0], nhw[0], nm[0], nm2[0]);
+    fetch_next(nd[1], nz[1], nhv[1], nhw[1], nm[1], nm2[1]);
     for (long long e = gw; e < n; e += nw) {
         float Gv[VPL][VEC], dGv[VPL][VEC];
 #pragma unroll
@@ -1028,18 +1050,21 @@ __global__ __launch_bounds__(kBlock) void actor_l1_bwd_k(const float* __restrict
         }
         for (int i = 0; i < N; ++i) {
             const long long r = e * N + i;
-            float d[VPL][VEC];
+            float d[VPL][VEC], u0[VPL][VEC];
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) { d[v][j] = nd[0][v][j]; nd[0][v][j] = nd[1][v][j]; }
+                for (int j = 0; j < VEC; ++j) {
+                    d[v][j] = nd[0][v][j]; nd[0][v][j] = nd[1][v][j];
+                    u0[v][j] = nz[0][v][j]; nz[0][v][j] = nz[1][v][j];
+                }
             const float hv = nhv[0], hw = nhw[0];
             float mean_in = 0.f, rstd_in = 1.f;
             if (stats) { mean_in = (float)nm[0]; rstd_in = 1.0f / sqrtf((float)(nm2[0] * (1.0 / (double)D)) + eps_in); }
             nhv[0] = nhv[1]; nhw[0] = nhw[1]; nm[0] = nm[1]; nm2[0] = nm2[1];
-            fetch_next(nd[1], nhv[1], nhw[1], nm[1], nm2[1]);   // row t+2 (row t+1 is already in flight)
+            fetch_next(nd[1], nz[1], nhv[1], nhw[1], nm[1], nm2[1]);   // row t+2 (row t+1 is already in flight)
             float zr[VPL][VEC], a[VPL][VEC];
-            l1_row_z<VEC, VPL>(Wt, H, HD, hv, hw, mean_in, rstd_in, Gv, sv, cv, cb, ok, zr);
+            l1_row_z<VEC, VPL>(Wt, H, HD, hv, hw, mean_in, rstd_in, Gv, sv, cv, cb, ok, u0, zr);
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
 #pragma unroll
@@ -1320,23 +1345,29 @@ DCC_API int dcc_rollout_record(const float* reward, const uint8_t* done, float* 
     return launch_status(__func__);
 }
 
-DCC_API int dcc_actor_l1_fwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
-                             const float* c, const float* gamma, const float* beta, float eps_in, float eps_ln,
-                             int32_t D, float* h, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
-    if (!head || !G || !Wh || !s || !c || !gamma || !beta || !h || n < 1 || N < 1 || D < 1) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
+}  // extern "C"
+
+namespace {
+
+// pre == NULL: the per-row term is head . Wh^T, formed in the kernel; pre != NULL (HD = 0): it is read from pre [n*N, H]
+int l1_fwd_impl(const char* fn, const float* head, const float* pre, const float* G, const double* stats, const float* Wh,
+                const float* s, const float* c, const float* gamma, const float* beta, float eps_in, float eps_ln,
+                int32_t D, float* h, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
+    if ((!pre && (!head || !Wh)) || !G || !s || !c || !gamma || !beta || !h || n < 1 || N < 1 || D < 1) return dcc_fail(kEINVAL, std::string(fn) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     Shape sh;
-    if (!pick_shape(H, sh) || HD < 0 || HD > kHdMax || pad_hd(HD) < 0) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (!pick_shape(H, sh) || HD < 0 || HD > kHdMax || pad_hd(HD) < 0) return dcc_fail(kEUNSUPPORTED, std::string(fn) + ": shape outside the compiled variants (hidden width / head width / output width)");
     const size_t lds = (size_t)HD * H * sizeof(float);
-    if (lds > kLdsMax) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (lds > kLdsMax) return dcc_fail(kEUNSUPPORTED, std::string(fn) + ": shape outside the compiled variants (hidden width / head width / output width)");
     if (lds > 64 * 1024) {
         const bool okl = sh.vec == 4 ? (sh.vpl == 1 ? allow_lds(actor_l1_fwd_k<4, 1>, lds) : allow_lds(actor_l1_fwd_k<4, 2>, lds))
                                      : (sh.vpl == 1 ? allow_lds(actor_l1_fwd_k<1, 1>, lds) : allow_lds(actor_l1_fwd_k<1, 2>, lds));
-        if (!okl) return dcc_fail(kEHIP, std::string(__func__) + ": could not raise the dynamic LDS limit");
+        if (!okl) return dcc_fail(kEHIP, std::string(fn) + ": could not raise the dynamic LDS limit");
     }
-    if (sh.vec == 4 && !(aligned16(G) && aligned16(h) && aligned16(gamma) && aligned16(beta) && aligned16(s) && aligned16(c)))
-        return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
+    if (pre && HD != 0) return dcc_fail(kEINVAL, std::string(fn) + ": a ready-made per-row term excludes head columns (HD must be 0)");
+    if (sh.vec == 4 && !(aligned16(G) && aligned16(h) && aligned16(gamma) && aligned16(beta) && aligned16(s) && aligned16(c) && aligned16(pre)))
+        return dcc_fail(kEINVAL, std::string(fn) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
-    if (H == 256 && HD == 4 + 2 * (N - 1) && (N == 8 || N == 4) && aligned16(stats) && aligned16(head)) {
+    if (!pre && H == 256 && HD == 4 + 2 * (N - 1) && (N == 8 || N == 4) && aligned16(stats) && aligned16(head)) {
         // BASELINE sizes: Wh^T in registers, inputs fetched an env ahead (actor_l1_fwd_env_k)
         static int res8 = 0, res4 = 0;
         if (N == 8) {
@@ -1348,43 +1379,44 @@ DCC_API int dcc_actor_l1_fwd(const float* head, const float* G, const double* st
             hipLaunchKernelGGL((actor_l1_fwd_env_k<4>), dim3((int)waves_for(n, res4)), dim3(kBlock), 0, st_, head, G, stats, Wh, s, c, gamma,
                                beta, eps_in, eps_ln, (int)D, h, (long long)n);
         }
-        return launch_status(__func__);
+        return launch_status(fn);
     }
     const int grid = (int)waves_for(n, kL1Blocks * 2);
-    LAUNCH_SHAPE(actor_l1_fwd_k, grid, lds, head, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, (int)D, h,
+    LAUNCH_SHAPE(actor_l1_fwd_k, grid, lds, head, pre, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, (int)D, h,
                  (long long)n, (int)N, (int)HD, (int)H);
-    return launch_status(__func__);
+    return launch_status(fn);
 }
 
-DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
-                             const float* c, const float* gamma, const float* dh, float eps_in, float eps_ln, int32_t D,
-                             float* dG, float* dWh, float* dq, float* ds, float* dc, float* dgamma, float* dbeta,
-                             float* workspace, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
-    if (!head || !G || !Wh || !s || !c || !gamma || !dh || !dG || (HD > 0 && !dWh && !dq) || !ds || !dc || !dgamma || !dbeta ||
+
+int l1_bwd_impl(const char* fn, const float* head, const float* pre, const float* G, const double* stats, const float* Wh,
+                const float* s, const float* c, const float* gamma, const float* dh, float eps_in, float eps_ln, int32_t D,
+                float* dG, float* dWh, float* dq, float* ds, float* dc, float* dgamma, float* dbeta, float* workspace,
+                int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
+    if ((!pre && (!head || !Wh)) || (pre && (HD != 0 || !dq)) || !G || !s || !c || !gamma || !dh || !dG || (HD > 0 && !dWh && !dq) || !ds || !dc || !dgamma || !dbeta ||
         !workspace || n < 1 || N < 1 || D < 1)
-        return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
+        return dcc_fail(kEINVAL, std::string(fn) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     Shape sh;
     const int hdp = pad_hd(HD);
-    if (!pick_shape(H, sh) || HD < 0 || HD > kHdMax || hdp < 0) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
-    if (hdp == kHdQOnly && !dq) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": more than 40 head columns need the q-storing form (dq != NULL)");
+    if (!pick_shape(H, sh) || HD < 0 || HD > kHdMax || hdp < 0) return dcc_fail(kEUNSUPPORTED, std::string(fn) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (hdp == kHdQOnly && !dq) return dcc_fail(kEUNSUPPORTED, std::string(fn) + ": more than 40 head columns need the q-storing form (dq != NULL)");
     const size_t lds = (size_t)HD * H * sizeof(float);
-    if (lds > kLdsMax) return dcc_fail(kEUNSUPPORTED, std::string(__func__) + ": shape outside the compiled variants (hidden width / head width / output width)");
+    if (lds > kLdsMax) return dcc_fail(kEUNSUPPORTED, std::string(fn) + ": shape outside the compiled variants (hidden width / head width / output width)");
     if (lds > 64 * 1024) {
         const bool okl = sh.vec == 4 ? (sh.vpl == 1 ? allow_lds(actor_l1_bwd_k<4, 1, 0>, lds) : allow_lds(actor_l1_bwd_k<4, 2, 0>, lds))
                                      : (sh.vpl == 1 ? allow_lds(actor_l1_bwd_k<1, 1, 0>, lds) : allow_lds(actor_l1_bwd_k<1, 2, 0>, lds));
-        if (!okl) return dcc_fail(kEHIP, std::string(__func__) + ": could not raise the dynamic LDS limit");
+        if (!okl) return dcc_fail(kEHIP, std::string(fn) + ": could not raise the dynamic LDS limit");
     }
     if (sh.vec == 4 && !(aligned16(G) && aligned16(dh) && aligned16(dG) && aligned16(gamma) && aligned16(s) &&
-                         aligned16(c) && aligned16(workspace)))
-        return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
+                         aligned16(c) && aligned16(workspace) && aligned16(pre)))
+        return dcc_fail(kEINVAL, std::string(fn) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
     const int grid = (int)waves_for(n, kL1Blocks);
     int hdp_used = hdp;
     int grid_used = grid;
-    const bool env_ok = H == 256 && HD == 4 + 2 * (N - 1) && (N == 8 || N == 4) && aligned16(stats) && aligned16(head);
+    const bool env_ok = !pre && H == 256 && HD == 4 + 2 * (N - 1) && (N == 8 || N == 4) && aligned16(stats) && aligned16(head);
     bool done_launch = false;
     if (env_ok) {   // BASELINE sizes: actor_l1_bwd_env_k (Wh^T in registers, env-ahead prefetch), grid = what is co-resident
-        if (dq && sh.vec == 4 && !aligned16(dq)) return dcc_fail(kEINVAL, std::string(__func__) + ": dq must be 16-byte aligned");
+        if (dq && sh.vec == 4 && !aligned16(dq)) return dcc_fail(kEINVAL, std::string(fn) + ": dq must be 16-byte aligned");
         static int res[4] = {0, 0, 0, 0};
         const int v = (N == 8 ? 0 : 1) + (dq ? 0 : 2);
         const void* fns[4] = {reinterpret_cast<const void*>(&actor_l1_bwd_env_k<8, false>), reinterpret_cast<const void*>(&actor_l1_bwd_env_k<4, false>),
@@ -1400,16 +1432,16 @@ DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* st
         hdp_used = dq ? 0 : HD;
         done_launch = true;
     } else if (dq) {   // two-kernel variant: light registers -> full occupancy, so use the larger grid too
-        if (sh.vec == 4 && !aligned16(dq)) return dcc_fail(kEINVAL, std::string(__func__) + ": dq must be 16-byte aligned");
+        if (sh.vec == 4 && !aligned16(dq)) return dcc_fail(kEINVAL, std::string(fn) + ": dq must be 16-byte aligned");
         grid_used = (int)waves_for(n, kL1Blocks * 2);
-        launch_l1_bwd<0>(sh, grid_used, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H);
+        launch_l1_bwd<0>(sh, grid_used, lds, st_, head, pre, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H);
     } else {
         switch (hdp) {
-            case 0: launch_l1_bwd<0>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
-            case 8: launch_l1_bwd<8>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
-            case 16: launch_l1_bwd<16>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
-            case 24: launch_l1_bwd<24>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
-            default: launch_l1_bwd<40>(sh, grid, lds, st_, head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+            case 0: launch_l1_bwd<0>(sh, grid, lds, st_, head, pre, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+            case 8: launch_l1_bwd<8>(sh, grid, lds, st_, head, pre, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+            case 16: launch_l1_bwd<16>(sh, grid, lds, st_, head, pre, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+            case 24: launch_l1_bwd<24>(sh, grid, lds, st_, head, pre, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
+            default: launch_l1_bwd<40>(sh, grid, lds, st_, head, pre, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, (int)D, dG, dq, workspace, (long long)n, (int)N, (int)HD, (int)H); break;
         }
     }
     (void)done_launch;
@@ -1418,7 +1450,41 @@ DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* st
     const long long nseg = reduce_stage1(workspace, (long long)grid_used * kWavesPerBlock, P, P, st_);
     hipLaunchKernelGGL(l1_reduce_k, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, workspace, nseg,
                        (long long)kSegWaves * P, hdp_used, (int)HD, (int)H, dWh, ds, dc, dgamma, dbeta);
-    return launch_status(__func__);
+    return launch_status(fn);
+}
+
+}  // namespace
+
+extern "C" {
+
+DCC_API int dcc_actor_l1_fwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
+                             const float* c, const float* gamma, const float* beta, float eps_in, float eps_ln,
+                             int32_t D, float* h, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
+    return l1_fwd_impl(__func__, head, nullptr, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, D, h, n, N, HD, H, stream);
+}
+
+DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* stats, const float* Wh, const float* s,
+                             const float* c, const float* gamma, const float* dh, float eps_in, float eps_ln, int32_t D,
+                             float* dG, float* dWh, float* dq, float* ds, float* dc, float* dgamma, float* dbeta,
+                             float* workspace, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream) {
+    return l1_bwd_impl(__func__, head, nullptr, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, D, dG, dWh, dq, ds, dc, dgamma,
+                       dbeta, workspace, n, N, HD, H, stream);
+}
+
+DCC_API int dcc_actor_l1_pre_fwd(const float* pre, const float* G, const double* stats, const float* s, const float* c,
+                                 const float* gamma, const float* beta, float eps_in, float eps_ln, int32_t D, float* h,
+                                 int64_t n, int32_t N, int32_t H, void* stream) {
+    if (!pre) return dcc_fail(kEINVAL, std::string(__func__) + ": pre must not be NULL");
+    return l1_fwd_impl(__func__, nullptr, pre, G, stats, nullptr, s, c, gamma, beta, eps_in, eps_ln, D, h, n, N, 0, H, stream);
+}
+
+DCC_API int dcc_actor_l1_pre_bwd(const float* pre, const float* G, const double* stats, const float* s, const float* c,
+                                 const float* gamma, const float* dh, float eps_in, float eps_ln, int32_t D, float* dG,
+                                 float* dpre, float* ds, float* dc, float* dgamma, float* dbeta, float* workspace, int64_t n,
+                                 int32_t N, int32_t H, void* stream) {
+    if (!pre || !dpre) return dcc_fail(kEINVAL, std::string(__func__) + ": pre and dpre must not be NULL");
+    return l1_bwd_impl(__func__, nullptr, pre, G, stats, nullptr, s, c, gamma, dh, eps_in, eps_ln, D, dG, nullptr, dpre, ds, dc,
+                       dgamma, dbeta, workspace, n, N, 0, H, stream);
 }
 
 }  // extern "C"

@@ -43,7 +43,8 @@ class EnvOut(ctypes.Structure):
 EXPORTS = ["dcc_obs_expand", "dcc_gae_compute", "dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
            "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout", "dcc_env_get_state",
            "dcc_env_set_state", "dcc_env_bytes_per_step", "dcc_obs_features", "dcc_obs_features_x",
-           "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_relu_ln_head_fwd", "dcc_relu_ln_head_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd", "dcc_ppo_policy_loss",
+           "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_relu_ln_head_fwd", "dcc_relu_ln_head_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd", "dcc_actor_l1_pre_fwd", "dcc_actor_l1_pre_bwd",
+           "dcc_ppo_policy_loss",
            "dcc_rollout_sample", "dcc_rollout_record", "dcc_ppo_value_loss",
            "dcc_grad_norm_workspace_floats", "dcc_grad_norm_clip", "dcc_adam_step"]
 
@@ -93,6 +94,8 @@ def load_library(path=None):
     L.dcc_mlp_workspace_floats.restype = i64
     L.dcc_actor_l1_fwd.argtypes = [_vp] * 8 + [f32, f32, i32, _vp, i64, i32, i32, i32, _vp]
     L.dcc_actor_l1_bwd.argtypes = [_vp] * 8 + [f32, f32, i32] + [_vp] * 8 + [i64, i32, i32, i32, _vp]
+    L.dcc_actor_l1_pre_fwd.argtypes = [_vp] * 7 + [f32, f32, i32, _vp, i64, i32, i32, _vp]
+    L.dcc_actor_l1_pre_bwd.argtypes = [_vp] * 7 + [f32, f32, i32] + [_vp] * 7 + [i64, i32, i32, _vp]
     L.dcc_grad_norm_workspace_floats.argtypes = [i64]
     L.dcc_grad_norm_workspace_floats.restype = i64
     L.dcc_grad_norm_clip.argtypes = [_vp, i64, f32, _vp, _vp, _vp]
@@ -525,6 +528,42 @@ def actor_l1_bwd(head, G, stats, Wh, s, c, gamma, dh, eps_in, eps_ln, D, two_ker
         else:
             dWh = dq.t() @ hf
     return dG, dWh, vecs[0], vecs[1], vecs[2], vecs[3]
+
+
+def actor_l1_pre_fwd(pre, G, stats, s, c, gamma, beta, eps_in, eps_ln, D):
+    """The first block with the per-row term ready-made: pre [n*N, H] (= head . Wh^T from a library GEMM), G [n, H]."""
+    n, H = G.shape
+    R = pre.shape[0]
+    N = R // n
+    if pre.shape != (n * N, H):
+        raise ValueError("pre must be [n*N, H] for G [n, H]")
+    for t, nm in ((pre, "pre"), (G, "G"), (s, "s"), (c, "c"), (gamma, "gamma"), (beta, "beta")):
+        _f32c(t, nm)
+    if stats is not None and (stats.dtype != torch.float64 or not stats.is_contiguous()):
+        raise ValueError("stats must be contiguous float64")
+    h = torch.empty((R, H), dtype=torch.float32, device=G.device)
+    with torch.cuda.device(G.device):
+        _check(load_library().dcc_actor_l1_pre_fwd(_ptr(pre), _ptr(G), _ptr(stats), _ptr(s), _ptr(c), _ptr(gamma), _ptr(beta),
+                                                   eps_in, eps_ln, D, _ptr(h), n, N, H, _stream()), "dcc_actor_l1_pre_fwd")
+    return h
+
+
+def actor_l1_pre_bwd(pre, G, stats, s, c, gamma, dh, eps_in, eps_ln, D):
+    """-> dpre [n*N, H], dG [n, H], ds, dc, dgamma, dbeta."""
+    n, H = G.shape
+    R = pre.shape[0]
+    N = R // n
+    L = load_library()
+    dev = G.device
+    dG = torch.empty_like(G)
+    dpre = torch.empty((R, H), dtype=torch.float32, device=dev)
+    vecs = torch.empty((4, H), dtype=torch.float32, device=dev)     # ds, dc, dgamma, dbeta
+    ws = torch.empty(L.dcc_mlp_workspace_floats(H, 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(L.dcc_actor_l1_pre_bwd(_ptr(pre), _ptr(G), _ptr(stats), _ptr(s), _ptr(c), _ptr(gamma), _ptr(_f32c(dh, "dh")),
+                                      eps_in, eps_ln, D, _ptr(dG), _ptr(dpre), _ptr(vecs[0]), _ptr(vecs[1]), _ptr(vecs[2]),
+                                      _ptr(vecs[3]), _ptr(ws), n, N, H, _stream()), "dcc_actor_l1_pre_bwd")
+    return dpre, dG, vecs[0], vecs[1], vecs[2], vecs[3]
 
 
 # ---- fused optimizer step on flat storage (include/dcc_optim.h) ------------------------------------------------------

@@ -135,6 +135,24 @@ DCC_API int dcc_actor_l1_bwd(const float* head, const float* G, const double* st
                              float* dG, float* dWh, float* dq, float* ds, float* dc, float* dgamma, float* dbeta,
                              float* workspace, int64_t n, int32_t N, int32_t HD, int32_t H, void* stream);
 
+/*
+ * The same block with the per-row head term supplied by the caller:
+ *   pre [n*N,H] f32 = head . Wh^T   (a library GEMM over the [n*N,HD] head values; its autograd owns dWh)
+ *   z = rstd_in * (pre[r] + G[e] - mean_in s) + c;   h = LayerNorm(ReLU(z))
+ * This is the form for MANY UAVs: the kernels above keep Wh^T in registers up to 8 UAVs and in LDS beyond, where HD reads of
+ * it per lane and row bound them (16 UAVs: 4.2 ms for 2.5 M rows); with the product done on the MFMA pipes the kernel is two
+ * streaming passes over [rows,H] and knows no limit on the number of UAVs.
+ * Backward given dh [n*N,H]: dpre [n*N,H] = rstd_in * dL/dz (the gradient of the GEMM output), dG [n,H], ds, dc, dgamma, dbeta
+ * [H]; workspace: dcc_mlp_workspace_floats(H, 1) floats.
+ */
+DCC_API int dcc_actor_l1_pre_fwd(const float* pre, const float* G, const double* stats, const float* s, const float* c,
+                                 const float* gamma, const float* beta, float eps_in, float eps_ln, int32_t D, float* h,
+                                 int64_t n, int32_t N, int32_t H, void* stream);
+DCC_API int dcc_actor_l1_pre_bwd(const float* pre, const float* G, const double* stats, const float* s, const float* c,
+                                 const float* gamma, const float* dh, float eps_in, float eps_ln, int32_t D, float* dG,
+                                 float* dpre, float* ds, float* dc, float* dgamma, float* dbeta, float* workspace, int64_t n,
+                                 int32_t N, int32_t H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

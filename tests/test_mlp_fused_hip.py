@@ -131,6 +131,18 @@ def test_actor_first_block_matches_torch(N, M, H, n, feature_norm):
         _close_grad(a, d, "grad(dense) " + name, n * N * H)
     o_f2, g_f2 = run(True)
     assert torch.equal(o_f, o_f2) and all(torch.equal(a, b) for a, b in zip(g_f, g_f2))
+    if lay.HD > fused.PRE_GEMM_ABOVE_HD:
+        # more than 8 UAVs: the default forms head . Wh^T with a library GEMM (dcc_actor_l1_pre_*); the in-kernel form of the
+        # same block (Wh^T in LDS, dcc_actor_l1_*) stays available behind the C-ABI and must agree
+        keep = fused.PRE_GEMM_ABOVE_HD
+        fused.PRE_GEMM_ABOVE_HD = 10 ** 9
+        try:
+            o_k, g_k = run(True)
+        finally:
+            fused.PRE_GEMM_ABOVE_HD = keep
+        _close(o_f, o_k, "GEMM-assisted vs in-kernel head term", rtol=1e-4, atol=1e-5)
+        for (name, _), a, b in zip(base.named_parameters(), g_f, g_k):
+            _close_grad(a, b, "grad(in-kernel) " + name, n * N * H)
 
 
 def test_shapes_outside_the_compiled_variants_are_refused():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates dynamic-coverage-control_amd/config/gemm_tunings_gfx950.csv: one MAPPO iteration per BASELINE shape with torch's
 # TunableOp tuning every library GEMM it meets (eager rollout: nothing may be tuned under stream capture), results merged
-# into one file.  Run on the GPU box (about 10 minutes): bash tools/tune_gemms.sh
+# into one file.  Run on the GPU box (about 15 minutes): bash tools/tune_gemms.sh
 set -e
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/gemm_tunings
@@ -13,4 +13,5 @@ run() { timeout 1500 python bench.py --mode mappo --iters 1 --no-graph "$@" > gp
 run                                                        # c3: 8 x 64 x 4096 envs
 run --agents 16 --pois 256 --envs 1024                     # c4 per-GPU shard
 run --agents 32 --pois 1024 --envs 256 --comm-force-scale 0.5 --r-comm 0.1   # c5 shape, 256 envs
+run --agents 32 --pois 1024 --envs 2048 --comm-force-scale 0.5 --r-comm 0.1  # c5 per-GPU shard (two chunks per epoch)
 cp ${OUT}0.csv dynamic-coverage-control_amd/config/gemm_tunings_gfx950.csv
