@@ -3,6 +3,7 @@ imported from /root/reference/uav_dcc_control) on a rollout of the REFERENCE env
 observation rows -- the fixture the structured-input path (first layers from env-state features) is checked against directly.
 Container-only; the outputs are data.  Re-run: python tools/gen_golden_mappo_env.py [small|n8m64]
 Second case `n8m64` (tests/golden/mappo_env_n8m64.npz): the BASELINE c2/c3 shape, 8 UAV x 64 PoI, E=2, T=31, hidden 32.
+Third case `n12m24`: 12 UAVs (more than 8: the learner's first block forms head . Wh^T with a library GEMM), 24 PoI, E=2, T=20.
 
 4 UAV x 20 PoI (shipped world constants), E=3 envs, T=34 steps (env 1 flies east and finishes at step 30: one episode end + auto-reset), hidden 32, ppo_epoch 2.  Contents:
   poi [M,2]; state_pos/state_vel [T+1,E,N,2] f64, state_energy [T+1,E,M] f32, state_done [T+1,E,M] u8: the env state each
@@ -24,7 +25,7 @@ sys.path.insert(0, HERE)
 from ref_harness import make_reference_env  # noqa: E402  (installs the gym stub, puts the reference on sys.path)
 
 REF = "/root/reference/uav_dcc_control"
-CASES = {"small": (4, 20, 3, 34, 32), "n8m64": (8, 64, 2, 31, 32)}     # N, M, E, T, H
+CASES = {"small": (4, 20, 3, 34, 32), "n8m64": (8, 64, 2, 31, 32), "n12m24": (12, 24, 2, 20, 32)}     # N, M, E, T, H
 
 
 class Box:
