@@ -46,12 +46,13 @@ def use_tuned_gemms(path=None):
     if _tuned_gemms is not None and path is None:
         return _tuned_gemms
     n = 0
+    path = path or os.environ.get("DCC_TUNED_GEMMS_FILE") or TUNED_GEMMS_FILE      # the env override is for A/B runs
     if (_use_gpu and os.environ.get("DCC_TUNED_GEMMS", "1") != "0" and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ
-            and os.path.exists(path or TUNED_GEMMS_FILE)):
+            and os.path.exists(path)):
         import torch.cuda.tunable as tun
         tun.enable(True)
         tun.tuning_enable(False)
-        if tun.read_file(path or TUNED_GEMMS_FILE):
+        if tun.read_file(path):
             n = len(tun.get_results())
         else:
             tun.enable(False)
