@@ -1,7 +1,6 @@
 """-m gpu: the HIP GAE scan (include/dcc_gae.h) against the reference's golden returns and the
 numpy oracle -- bit-exact float32."""
 import os
-from argparse import Namespace
 
 import numpy as np
 import pytest

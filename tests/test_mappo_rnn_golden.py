@@ -2,7 +2,6 @@
 r_actor_critic.py with use_recurrent_policy / use_naive_recurrent_policy) against fixtures produced by the reference
 itself (tools/gen_golden_mappo_rnn.py).  CPU torch: host-side logic; the device run is in test_learner_hip.py."""
 import os
-from argparse import Namespace
 
 import numpy as np
 import pytest

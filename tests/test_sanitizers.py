@@ -10,7 +10,6 @@ fused rollouts of the role-specialised and split kernels against the single-wave
 many envs and several action streams -- a lost or early hand-off shows up as a differing observation row or output."""
 import os
 import subprocess
-import sys
 
 import numpy as np
 import pytest

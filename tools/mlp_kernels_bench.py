@@ -1,7 +1,7 @@
 """Time the fused policy-trunk kernels (include/dcc_mlp.h) at the c3 update shapes on the GPU box:
 R = 150 x 4096 x 8 agent rows, H = 256.  Prints ms per call and the algorithmic HBM rate of each."""
 import os, sys, time
-import numpy as np, torch
+import torch
 R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R_, "dynamic-coverage-control_amd"))
 import dcc_hip
