@@ -78,7 +78,7 @@ def test_unsupported_width_falls_back_to_torch_ops():
 
 
 @pytest.mark.parametrize("feature_norm", [True, False])
-@pytest.mark.parametrize("N,M,H,n", [(8, 64, 256, 517), (4, 20, 64, 33), (1, 9, 32, 5), (5, 37, 128, 70), (16, 256, 256, 40),
+@pytest.mark.parametrize("N,M,H,n", [(8, 64, 256, 517), (4, 20, 256, 301), (4, 20, 64, 33), (1, 9, 32, 5), (5, 37, 128, 70), (16, 256, 256, 40),
                                      (11, 30, 256, 19), (32, 100, 256, 23), (20, 30, 64, 9), (63, 40, 256, 6)])
 def test_actor_first_block_matches_torch(N, M, H, n, feature_norm):
     """fused actor L1 (from dcc_obs_features of random states) == the torch formulation of structured.actor_trunk's
@@ -217,7 +217,7 @@ def test_split_k_linear_matches_plain(R, K, H):
     _close(W1.grad, W2.grad, "dW", rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("n,N,H", [(517, 8, 256), (33, 4, 64), (8200, 8, 64)])
+@pytest.mark.parametrize("n,N,H", [(517, 8, 256), (1003, 4, 256), (33, 4, 64), (8200, 8, 64)])
 def test_actor_l1_backward_one_and_two_kernel_variants_agree(n, N, H):
     """dq == NULL (dWh accumulated in registers) and dq != NULL (q stored, dWh = q^T head as a batched GEMM) are the
     same gradients; the second is what long batches use."""
