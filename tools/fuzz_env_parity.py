@@ -1,7 +1,7 @@
 """Differential fuzz of the env kernels against the oracle (test infrastructure, like tests/): random sizes, radii, force
 scales, env counts, action scales and kernel forms (fused / role-specialised / split, compile-time and runtime sizes, single
 steps and fused K-step rollouts) for a wall-clock budget.  Masks, assignment indices, energies and coverage must be bit-equal,
-positions / rewards within the tests' tolerances.  Run on the GPU box: python tools/fuzz_env_parity.py [seconds] [seed]"""
+positions / rewards within the tests' tolerances.  Run on the GPU box: python tools/fuzz_env_parity.py [seconds] [seed] [max N*M]"""
 import os, sys, time
 import numpy as np
 import torch
@@ -15,6 +15,7 @@ from oracle import oracle
 POS_TOL, OBS_TOL = 1e-9, 2e-6
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+LIMIT = int(sys.argv[3]) if len(sys.argv) > 3 else 40000
 oracle.build()
 t0 = time.time()
 cases = steps = 0
@@ -22,7 +23,7 @@ forms = {}
 while time.time() - t0 < budget:
     N = int(rs.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32, 33, 48, 64]))
     M = int(rs.choice([1, 2, 7, 16, 20, 37, 63, 64, 65, 100, 128, 129, 200, 256, 300, 511, 512, 700, 1024]))
-    if N * M > 40000:
+    if N * M > LIMIT:
         continue
     E = int(rs.choice([1, 2, 3, 4, 5, 7, 8, 31, 33, 64, 65])) if N * M < 20000 else int(rs.choice([1, 3, 5]))
     cfs = float(rs.choice([0.0, 0.0, 0.5, 1.0, rs.uniform(0.1, 2.0)]))
