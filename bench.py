@@ -204,7 +204,7 @@ def bench_mappo(args):
            "scaling": "weak", "vs_baseline": None, "dtype": "f64 env state / f32 MLPs", "data": "synthetic",
            "config": m}
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        _emit_json(res)
     return res
 
 
@@ -282,6 +282,26 @@ def _self_launch(n):
     os.execv(sys.executable, cmd)
 
 
+_JSON_OUT = None
+
+
+def _claim_stdout():
+    """stdout carries the ONE JSON line and nothing else: file descriptor 1 is pointed at stderr for everything this process
+    (Python or native libraries) prints on the way, the line itself goes to the original descriptor."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+        sys.stdout = sys.stderr
+
+
+def _emit_json(res):
+    out = _JSON_OUT or sys.stdout
+    out.write(json.dumps(res) + "\n")
+    out.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,6 +342,7 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         _self_launch(args.gpus)
+    _claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -458,7 +479,7 @@ def main():
 
     def emit():
         if rank == 0:
-            print(json.dumps(res), flush=True)
+            _emit_json(res)
 
     if not args.no_c3:
         # bounded config-3 leg.  It must never cost the headline line: a watchdog prints the line without `c3` and ends

@@ -20,8 +20,8 @@ def _run(args, env=None, launcher=None):
     cmd = (launcher or [sys.executable]) + ["bench.py"] + args
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-1000:]          # exactly ONE JSON line
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-1000:]          # exactly ONE line on stdout, the JSON line
     return json.loads(lines[0])
 
 
@@ -78,8 +78,8 @@ def test_gpus_2_launches_itself():
            "--c3-iters", "1", "--ppo-epoch", "2"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(env, DCC_BENCH_BACKEND="gloo"))
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-1000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-1000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2048 and d["config"]["envs_per_gpu"] == 1024
     assert "cpu_baseline" not in d and d["scaling"] == "weak"
