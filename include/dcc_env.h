@@ -31,6 +31,9 @@ extern "C" {
 #define DCC_API
 #endif
 
+/* Bumped when a struct layout or the meaning of an existing entry point changes; entry points ADDED since (round 2:
+ * dcc_obs_features_x, dcc_grad_norm_clip / dcc_adam_step, dcc_actor_l1_pre_fwd / _bwd) leave it as it is -- a binding that needs
+ * one of them checks for the symbol. */
 #define DCC_ABI_VERSION 2
 
 #define DCC_OK 0
