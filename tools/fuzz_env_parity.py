@@ -1,7 +1,8 @@
 """Differential fuzz of the env kernels against the oracle (test infrastructure, like tests/): random sizes, radii, force
 scales, env counts, action scales and kernel forms (fused / role-specialised / split, compile-time and runtime sizes, single
 steps and fused K-step rollouts) for a wall-clock budget.  Masks, assignment indices, energies and coverage must be bit-equal,
-positions / rewards within the tests' tolerances.  Run on the GPU box: python tools/fuzz_env_parity.py [seconds] [seed] [max N*M]"""
+positions / rewards within the tests' tolerances; after every case the compact state is expanded to rows and reduced to the
+policy-input features (dcc_obs_expand / dcc_obs_features), which must match the features computed from the rows in float64.  Run on the GPU box: python tools/fuzz_env_parity.py [seconds] [seed] [max N*M]"""
 import os, sys, time
 import numpy as np
 import torch
@@ -11,6 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "dynamic-coverage-control_amd"))
 sys.path.insert(0, ROOT)
 import dcc_hip
 from oracle import oracle
+from algos.algo_utils.structured import ObsLayout, features_from_obs
 
 POS_TOL, OBS_TOL = 1e-9, 2e-6
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
@@ -68,6 +70,16 @@ while time.time() - t0 < budget:
             assert np.array_equal(st["done"].cpu().numpy(), so["done"]), "done state"
             t += k
             steps += k * E
+        # compact state -> observation rows and -> policy-input features (float64 moments of the float32 row values)
+        stt = [st[kk].contiguous() for kk in ("pos", "vel", "energy", "done")]
+        rows = env.expand_obs(*stt)
+        f = env.obs_features(*stt)
+        ref = features_from_obs(rows, ObsLayout(N, M, poi, env.m_energy))
+        assert torch.equal(f["head"], ref["head"]) and torch.equal(f["poi_feat"], ref["poi_feat"]), "features head / poi_feat"
+        np.testing.assert_allclose(f["stats"][..., 0].cpu().numpy(), ref["stats"][..., 0].cpu().numpy(), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(f["stats"][..., 1].cpu().numpy(), ref["stats"][..., 1].cpu().numpy(), rtol=1e-11)
+        np.testing.assert_allclose(f["cstats"][:, 0].cpu().numpy(), ref["cstats"][:, 0].cpu().numpy(), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(f["cstats"][:, 1].cpu().numpy(), ref["cstats"][:, 1].cpu().numpy(), rtol=1e-10)
     except Exception as e:  # noqa: BLE001
         print("MISMATCH in case", tag, "->", type(e).__name__, str(e)[:400], flush=True)
         sys.exit(1)
