@@ -143,7 +143,7 @@ def mappo_iterations(args, iters, warm_iters=2):
     for _ in range(warm_iters):  # hipBLASLt heuristics, allocator, eager rollout + hipGraph capture, first replay
         one_iter()
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DCC_DIST_SINGLE") == "1":   # the latter: a 1-rank group over RCCL on a 1-GPU box (test hook)
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
@@ -181,7 +181,7 @@ def mappo_iterations(args, iters, warm_iters=2):
            "update_s_per_iter": tu / iters, "rollout_agent_env_steps_per_sec": world * E * N * T / (tr / iters),
            "hip_graph_rollout": not args.no_graph, "rows_stored": bool(args.keep_rows), "structured_input": structured,
            "tuned_gemm_entries": lr.tuned_gemms,
-           "grad_allreduce": ("%s x%d" % ({"nccl": "rccl"}.get(dist.get_backend(), dist.get_backend()), world)) if world > 1 else "none (1 GPU)",
+           "grad_allreduce": ("%s x%d" % ({"nccl": "rccl"}.get(dist.get_backend(), dist.get_backend()), world)) if dist is not None else "none (1 GPU)",
            "mlp_tflop_per_iter_reference_formulation": ref_fwd * rows * (1 + 3 * args.ppo_epoch) / 1e12,
            "mlp_tflop_per_iter_as_evaluated": ours_fwd * rows * (1 + 3 * args.ppo_epoch) / 1e12,
            "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
@@ -358,9 +358,11 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DCC_DIST_SINGLE") == "1":   # the latter: a 1-rank group over RCCL on a 1-GPU box (test hook)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:

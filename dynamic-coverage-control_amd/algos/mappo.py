@@ -34,7 +34,7 @@ from utils.valuenorm import ValueNorm
 
 def _dist():
     import torch.distributed as dist
-    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+    return dist if ptu.dist_active() else None
 
 
 class MAPPOPolicy:

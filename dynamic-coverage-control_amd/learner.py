@@ -51,7 +51,8 @@ class Learner:
             # the recurrent variants (off in the shipped config) consume observation rows step by step: the rollout buffer
             # keeps rows and per-(env, agent) GRU states, and the critic runs once per agent row like in the reference
             self.cfg.structured_input = self.cfg.compact_obs = False
-        self.rank, self.world = ptu.init_distributed() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
+        self.rank, self.world = ptu.init_distributed() if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or ptu.single_rank_group()) else (0, 1)
+        self.dist_on = self.world > 1 or ptu.single_rank_group()
         utl.seed(self.cfg.seed + self.rank)
         # measured-fastest library GEMM per listed shape instead of the library heuristic's pick (lookup only)
         self.tuned_gemms = ptu.use_tuned_gemms() if getattr(self.cfg, "tuned_gemms", True) else 0
@@ -217,7 +218,7 @@ class Learner:
             self.total_env_steps += self.max_ep_len * r_envs.n_envs * self.world
         rew_acc, cov_max = stats           # reduced over the envs HERE, outside any captured graph
         stats = torch.stack([rew_acc.mean(), cov_max.double().mean()])
-        if self.world > 1:
+        if self.dist_on:
             import torch.distributed as dist
             dist.all_reduce(stats)
             stats /= self.world
@@ -349,7 +350,7 @@ class Learner:
         file; COLLECTIVE in a multi-GPU job: every rank must call it).  (The reference pickles the policy object only:
         ValueNorm, iteration and RNG are lost, uav_dcc_control/algos/mappo.py:237-247.)"""
         ranks = [self._rank_state()]
-        if self.world > 1:
+        if self.dist_on:
             import torch.distributed as dist
             gathered = [None] * self.world if self.rank == 0 else None
             dist.gather_object(ranks[0], gathered, dst=0)

@@ -66,11 +66,13 @@ def init_distributed(backend=None):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world == 1:
+    if world == 1 and not single_rank_group():
         return 0, 1
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1:
+        os.environ.setdefault("MASTER_PORT", "29571")
     if backend is None:   # DCC_DIST_BACKEND=gloo is a test hook: the ranks may then share one GPU (gloo moves CUDA tensors)
         backend = os.environ.get("DCC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
@@ -81,6 +83,20 @@ def init_distributed(backend=None):
             set_gpu_mode(True, int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world
+
+
+def single_rank_group():
+    """DCC_DIST_SINGLE=1 (a test hook for boxes with ONE GPU): bring up the process group with a single rank and take every
+    distributed code path anyway -- over backend "nccl" that runs communicator creation and each collective call site
+    (all-reduce sync / async, broadcast, gather_object, barrier) through RCCL on real hardware, which is where a tensor left
+    on the host or an operation the backend lacks would show."""
+    return os.environ.get("DCC_DIST_SINGLE") == "1"
+
+
+def dist_active():
+    """the process group is up and the distributed code paths are to be taken"""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_group())
 
 
 def world_size():

@@ -36,7 +36,8 @@ class ValueNorm(nn.Module):
         batch_mean = x.mean(dim=dims)
         batch_sq_mean = (x ** 2).mean(dim=dims)
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        import utils.pytorch_utils as ptu
+        if ptu.dist_active():
             both = torch.stack([batch_mean.reshape(-1), batch_sq_mean.reshape(-1)])
             dist.all_reduce(both)
             both /= dist.get_world_size()

@@ -20,6 +20,27 @@ def test_two_rank_gpu_training_keeps_replicas_identical():
     assert "DIST_GPU_OK" in r.stdout
 
 
+def test_single_rank_group_over_rccl():
+    """What a 1-GPU box can run of the RCCL path: a ONE-rank process group over backend nccl (DCC_DIST_SINGLE=1) through every
+    collective call site of the learner and of bench.py -- a host tensor handed to a collective or an operation RCCL lacks
+    fails here, not first on the 8-GPU node."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DCC_BENCH_BACKEND", "DCC_DIST_BACKEND")}
+    env.update(DCC_DIST_SINGLE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_single_worker.py")], cwd=ROOT, capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "RCCL_SINGLE_OK" in r.stdout
+    env["MASTER_PORT"] = "29548"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--launches-per-step", "4",
+                        "--c3-iters", "1", "--ppo-epoch", "2", "--envs", "1024", "--no-cpu-baseline"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and "error" not in d["c3"] and "error" not in d["c4"] and "error" not in d["c5"], (d["c3"], d["c4"], d["c5"])
+    assert d["c3"]["grad_allreduce"] == "rccl x1" and all(v == v for v in d["c3"]["train_info"].values())
+
+
 @pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two GPUs (the gpurun box has one)")
 def test_two_gpus_over_rccl():
     """Runs wherever >= 2 GPUs are visible: bench.py --gpus 2 launches itself, the ranks rendezvous over RCCL
