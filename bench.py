@@ -55,7 +55,7 @@ def _host_threads():
     return n
 
 
-def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, budget_s=10.0):
+def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, budget_s=10.0, E_thr=64, K=25, single_s=2.0, label="c2"):
     """Time the CPU restatement on a bounded sample of the same workload THROUGH THE SAME C-ABI as the GPU path: the
     `_cpu` twins of include/dcc_env.h (oracle/dcc_env_cpu.c: dcc_env_rollout_cpu with the product's dcc_env_cfg /
     dcc_env_out structs, host pointers).  Every host thread steps its own batch of 64 envs in fused rollouts of 25 steps
@@ -64,7 +64,6 @@ def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, budget_s=10.0):
     from oracle import oracle
     oracle.build()
     cores = _host_threads()
-    E_thr, K = 64, 25
 
     def make():
         e = oracle.CpuTwinEnv(E_thr, N, M, poi, r_cover, r_comm, crs, cfs)
@@ -74,7 +73,7 @@ def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, budget_s=10.0):
     o, out1 = make()
     t0 = time.perf_counter()
     n1 = 0
-    while time.perf_counter() - t0 < 2.0:
+    while time.perf_counter() - t0 < single_s:
         o.rollout(K, seed=0, step0=n1, out=out1)
         n1 += K
     rate1 = E_thr * n1 * N / (time.perf_counter() - t0)
@@ -104,9 +103,10 @@ def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, budget_s=10.0):
         model = "unknown"
     return {"value": value, "unit": "agent-env-steps/s", "cores": cores, "kind": "port",
             "sample": "oracle/dcc_env_cpu.c (the `_cpu` twins of include/dcc_env.h over the C restatement of the reference env, "
-                      "float64): dcc_env_rollout_cpu, %d threads x %d envs, %.0f s of the c2 workload (N=%d, M=%d; %d env-steps in "
+                      "float64): dcc_env_rollout_cpu, %d threads x %d envs, %.0f s of the %s workload (N=%d, M=%d%s; %d env-steps in "
                       "total) with the same counter-based random actions, observation rows written; single-thread rate %.0f "
-                      "agent-env-steps/s; host CPU: %s" % (cores, E_thr, dt, N, M, E_thr * sum(counts), rate1, model),
+                      "agent-env-steps/s; host CPU: %s" % (cores, E_thr, dt, label, N, M, ", pull force on" if cfs > 0 else "",
+                                                            E_thr * sum(counts), rate1, model),
             "value_1core": rate1}
 
 
@@ -181,6 +181,10 @@ def mappo_iterations(args, iters, warm_iters=2):
            "update_s_per_iter": tu / iters, "rollout_agent_env_steps_per_sec": world * E * N * T / (tr / iters),
            "hip_graph_rollout": not args.no_graph, "rows_stored": bool(args.keep_rows), "structured_input": structured,
            "tuned_gemm_entries": lr.tuned_gemms,
+           "tuned_gemm_warning": None if lr.tuned_gemms else (
+               "0 entries of config/gemm_tunings_gfx950.csv are in use (its validators -- torch / ROCm / rocBLAS / hipBLASLt "
+               "versions, GPU arch -- do not match this installation, or DCC_TUNED_GEMMS=0): the library heuristic picks the "
+               "GEMM kernels, expect ~6 % less on this leg; regenerate with tools/tune_gemms.sh"),
            "grad_allreduce": ("%s x%d" % ({"nccl": "rccl"}.get(dist.get_backend(), dist.get_backend()), world)) if dist is not None else "none (1 GPU)",
            "mlp_tflop_per_iter_reference_formulation": ref_fwd * rows * (1 + 3 * args.ppo_epoch) / 1e12,
            "mlp_tflop_per_iter_as_evaluated": ours_fwd * rows * (1 + 3 * args.ppo_epoch) / 1e12,
@@ -208,8 +212,19 @@ def bench_mappo(args):
     return res
 
 
+def _agree(dist, backend, dev, ok):
+    """True iff `ok` on every rank (one 1-element MIN all-reduce; no-op single process).  Called before a leg enters its
+    first collective, so a rank whose local set-up failed makes ALL ranks skip the leg instead of leaving the others
+    waiting in a barrier until the watchdog fires."""
+    if dist is None:
+        return bool(ok)
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
 def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, launches=12, warm=3, cfs=0.0, r_comm=0.4,
-                  name="c4 (BASELINE configs[3])"):
+                  name="c4 (BASELINE configs[3])", cpu=None):
     """Bounded env-step leg at another BASELINE shape with the JOB-WIDE env count fixed (strong scaling): BASELINE
     configs[3] is 16 UAV x 256 PoI x 8192 envs over the GPUs of the job, i.e. 8192 / world envs per GPU, no data-path
     collective.  `launches` fused launches of T steps (in-kernel action stream), HIP-event timed; value = job-wide
@@ -219,10 +234,21 @@ def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, la
         raise ValueError("%d envs do not divide over %d GPUs" % (E_total, world))
     E = E_total // world
     from envs.hip_vec_env import load_pois       # the reference's PoI table (+ seeded synthetic rows beyond its 1000)
-    env = dcc_hip.HipCoverageEnv(E, N, M, load_pois(M), 0.2, r_comm, 0.95, cfs, device=local_dev)
-    env.reset()
-    out = env.alloc_out(T)
     dev = torch.device("cuda", local_dev)
+    env = out = err = None
+    try:                                         # local set-up (allocations): no collective in here
+        env = dcc_hip.HipCoverageEnv(E, N, M, load_pois(M), 0.2, r_comm, 0.95, cfs, device=local_dev)
+        env.reset()
+        out = env.alloc_out(T)
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        err = e
+    if not _agree(dist, backend, dev, err is None):      # every rank skips the leg together
+        if env is not None:
+            env.close()
+        del env, out
+        torch.cuda.empty_cache()
+        raise RuntimeError("set-up failed on %s: %s" % ("this rank" if err is not None else "another rank", err))
 
     def go(n, step0, events=None):
         for i in range(n):
@@ -254,7 +280,15 @@ def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, la
     env.close()
     del env, out
     torch.cuda.empty_cache()
-    return {"workload": "%s: %d UAV x %d PoI x %d envs job-wide = %d per GPU over %d GPU(s), random-action env-step kernel%s, "
+    extra = {}
+    if cpu is not None and rank == 0 and world == 1:
+        # the CPU restatement at THIS (N, M) through the same C-ABI twins, single thread and all threads
+        try:
+            extra["cpu_baseline"] = cpu_baseline(N, M, load_pois(M), 0.2, r_comm, 0.95, cfs, label=name, **cpu)
+        except Exception as e:  # noqa: BLE001
+            extra["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    return {**extra,
+            "workload": "%s: %d UAV x %d PoI x %d envs job-wide = %d per GPU over %d GPU(s), random-action env-step kernel%s, "
                         "%d fused launches x %d steps, actions drawn in-kernel, obs written"
                         % (name, N, M, E_total, E, world, ", connectivity pull force on (comm_force_scale %.1f, r_comm %.2f)" % (cfs, r_comm) if cfs > 0 else "",
                            launches, T),
@@ -283,6 +317,8 @@ def _self_launch(n):
 
 
 _JSON_OUT = None
+_EMIT_LOCK = threading.Lock()
+_EMITTED = False
 
 
 def _claim_stdout():
@@ -297,9 +333,36 @@ def _claim_stdout():
 
 
 def _emit_json(res):
-    out = _JSON_OUT or sys.stdout
-    out.write(json.dumps(res) + "\n")
-    out.flush()
+    """The ONE JSON line: whoever comes first (the main thread or the watchdog) writes it, anyone later is a no-op."""
+    global _EMITTED
+    with _EMIT_LOCK:
+        if _EMITTED:
+            return False
+        _EMITTED = True
+        out = _JSON_OUT or sys.stdout
+        out.write(json.dumps(res) + "\n")
+        out.flush()
+        return True
+
+
+def rccl_proof(dist, backend, dev, rank, world, local_rank):
+    """What the N>1 line says about the job it ran as (rank 0 returns the dict): every rank contributes its identity
+    (all_gather_object), and an all-reduce of ones over the data-path backend must come back as the rank count."""
+    p = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": local_rank, "device": int(dev.index), "name": p.name,
+          "uuid": str(getattr(p, "uuid", "")), "pci_bus_id": getattr(p, "pci_bus_id", None), "pid": os.getpid()}
+    seen = [None] * world
+    dist.all_gather_object(seen, me)
+    ones = torch.ones(1024, dtype=torch.float32, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(ones)
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        ver = None
+    uu = [r["uuid"] or "%s:%s" % (r["pci_bus_id"], r["device"]) for r in seen]
+    return {"backend": {"nccl": "rccl"}.get(dist.get_backend(), dist.get_backend()), "rccl_version": ver,
+            "world_size": dist.get_world_size(), "ranks_seen": seen, "distinct_devices": len(set(uu)),
+            "allreduce_of_ones": float(ones[0].item()), "allreduce_ok": bool((ones == float(world)).all().item())}
 
 
 def main():
@@ -454,7 +517,7 @@ def main():
     alg = bstep * E * T
     ach = alg / (avg_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None  # HBM bytes per launch: OFFLINE rocprofv3 PMC passes of this workload, not this run
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic_c2.json")))
             w = tj["workload"]
@@ -472,7 +535,17 @@ def main():
                        "kernel": "dcc_env_roles_kernel<ACT,FORCE,NC,MC> (c2: <0,false,8,64>); DCC_NO_ROLES=1: dcc_env_kernel<1,0,false,8,64>",
                        "bytes_per_env_step": bstep, "timing": "HIP events around every timed launch on the launch stream",
                        "launch_ms_avg": avg_ms, "launch_ms_min": sms[0], "launch_ms_median": sms[len(sms) // 2],
-                       "launch_ms_max": sms[-1], "launches_timed": len(ms), "frac_of_achievable_6300": ach / 6300.0}
+                       "launch_ms_max": sms[-1], "launches_timed": len(ms), "frac_of_achievable_6300": ach / 6300.0,
+                       # the PHYSICAL rate: HBM bytes the counters saw per launch / launch time.  `frac` counts SURVEY 8d's
+                       # algorithmic bytes, which include per-step state reads / writes a fused K-step launch keeps in
+                       # registers, so it sits ~8 % above the physical fraction at c2
+                       "physical_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+                       "frac_physical": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None}
+    res["config"]["steps_unit"] = ("--steps / --warmup / `steps` / `warmup` count PASSES over one synthetic batch (= %d fused launches x %d "
+                                   "batched env steps each), not single env steps" % (L, T))
+    if dist is not None:
+        proof = rccl_proof(dist, backend, dev, rank, world, local_rank)
+        res["rccl"] = proof
     env.close()
     del env, out, actions
     torch.cuda.empty_cache()
@@ -484,30 +557,38 @@ def main():
             _emit_json(res)
 
     if not args.no_c3:
-        # bounded config-3 leg.  It must never cost the headline line: a watchdog prints the line without `c3` and ends
-        # the process if the leg hangs (e.g. a collective that never completes), exceptions are recorded as text.
+        # bounded legs at the other BASELINE configs.  They must never cost the headline line: a watchdog prints the line
+        # with what is there and ends the process if a leg hangs (e.g. a collective that never completes), exceptions are
+        # recorded as text, and a leg whose local set-up fails on one rank is skipped by all ranks (_agree).
         done = threading.Event()
+        current = ["-"]
 
         def watchdog():
             if not done.wait(args.c3_timeout):
-                res["c3"] = {"error": "timed out after %.0f s" % args.c3_timeout}
+                res.setdefault(current[0], {"error": "timed out after %.0f s (legs share one budget)" % args.c3_timeout})
                 emit()
                 os._exit(0)
 
         threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            res["c4"] = env_shape_leg(16, 256, 8192, world, rank, local_dev, dist, backend)
-        except Exception as e:  # noqa: BLE001
-            res["c4"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        try:   # BASELINE configs[4]: the branchy wavefront path (pull force on), 16384 envs job-wide; 664 KB of rows per env-step
-            res["c5"] = env_shape_leg(32, 1024, 16384, world, rank, local_dev, dist, backend, T=4, launches=8, warm=2, cfs=0.5,
-                                      r_comm=0.1, name="c5 (BASELINE configs[4])")
-        except Exception as e:  # noqa: BLE001
-            res["c5"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        try:
-            res["c3"] = mappo_iterations(args, args.c3_iters)
-        except Exception as e:  # noqa: BLE001
-            res["c3"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+        def leg(key, fn):
+            current[0] = key
+            try:
+                res[key] = fn()
+            except Exception as e:  # noqa: BLE001
+                res[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                torch.cuda.empty_cache()
+
+        if world > 1:   # BASELINE's metric reads "4096 envs; 1/2/4/8 GPU": the fixed-4096 (STRONG) c2 figure next to the weak `value`
+            leg("c2_strong", lambda: env_shape_leg(N, M, 4096, world, rank, local_dev, dist, backend, T=T, launches=16, warm=4, cfs=cfs,
+                                                   r_comm=r_comm, name="c2 strong (BASELINE configs[1] with the job-wide env count fixed)"))
+        leg("c4", lambda: env_shape_leg(16, 256, 8192, world, rank, local_dev, dist, backend,
+                                        cpu=None if args.no_cpu_baseline else dict(budget_s=4.0, E_thr=16, K=10, single_s=1.5)))
+        # BASELINE configs[4]: the branchy wavefront path (pull force on), 16384 envs job-wide; 664 KB of rows per env-step
+        leg("c5", lambda: env_shape_leg(32, 1024, 16384, world, rank, local_dev, dist, backend, T=4, launches=8, warm=2, cfs=0.5,
+                                        r_comm=0.1, name="c5 (BASELINE configs[4])",
+                                        cpu=None if args.no_cpu_baseline else dict(budget_s=4.0, E_thr=4, K=5, single_s=1.5)))
+        leg("c3", lambda: mappo_iterations(args, args.c3_iters))
         done.set()
     emit()
     if dist is not None:

@@ -29,6 +29,7 @@ class FlatAdam(torch.optim.Optimizer):
         if dt != torch.float32 or any(p.device != dev or p.dtype != dt for p in params):
             raise ValueError("FlatAdam: float32 parameters on one device")
         self._params = params
+        self._numels = [p.numel() for p in params]
         self._offsets, n = [], 0
         for p in params:
             self._offsets.append(n)
@@ -50,8 +51,31 @@ class FlatAdam(torch.optim.Optimizer):
 
     # padding between the views stays zero: zero gradient, zero moments -> Adam leaves it at zero
 
+    def _check_views(self):
+        """Every parameter must still BE its view into flat_param: the kernels update flat_param through raw pointers, so a
+        parameter whose storage was moved behind the optimizer's back (module.to(...) / any nn.Module._apply -- which also
+        makes nn.GRU.flatten_parameters() re-allocate its weights --, load_state_dict(assign=True), p.data = ...) would keep
+        computing with a detached tensor while the optimizer trains the orphaned view: training stalls silently.  Host-side
+        pointer compare only (no sync).  A moved parameter of unchanged shape / dtype / device is re-attached -- its
+        current values, the ones the network computes with, are copied into the view; anything else raises.  Do not call
+        .to() on a network after its optimizer was built."""
+        base = self.flat_param.data_ptr()
+        for p, off, numel in zip(self._params, self._offsets, self._numels):
+            if p.data_ptr() == base + 4 * off:
+                continue
+            view = self.flat_param[off:off + numel]
+            if p.device != view.device or p.dtype != view.dtype or p.numel() != numel:
+                raise RuntimeError("FlatAdam: a parameter left the optimizer's flat storage and changed device / dtype / size "
+                                   "(%s %s, expected %s %s); rebuild the optimizer after moving a network"
+                                   % (p.device, p.dtype, view.device, view.dtype))
+            with torch.no_grad():
+                view.copy_(p.data.reshape(-1))
+                p.data = view.view(p.shape)
+
     def zero_grad(self, set_to_none=False):
-        """One memset; the .grad views are re-attached if a caller dropped them (set_to_none elsewhere)."""
+        """One memset; the .grad views are re-attached if a caller dropped them (set_to_none elsewhere), and so are
+        parameters that left the flat storage (_check_views)."""
+        self._check_views()
         self.flat_grad.zero_()
         for p, off in zip(self._params, self._offsets):
             g = p.grad
@@ -65,6 +89,7 @@ class FlatAdam(torch.optim.Optimizer):
     def clip_and_step(self, max_norm=None):
         """clip_grad_norm_(params, max_norm) (None / <= 0: norm only) followed by one Adam step.  Returns the gradient
         norm BEFORE clipping as a 0-d device tensor (no sync)."""
+        self._check_views()
         g = self.param_groups[0]
         beta1, beta2 = g["betas"]
         self.step_count += 1

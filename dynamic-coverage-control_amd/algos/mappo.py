@@ -337,8 +337,13 @@ class MAPPOTrainer:
             # steps; the library GEMMs themselves stay correct there, tools/big_rows_probe.py).  The chunked step is exact
             # (gradient accumulation of a mean loss), so the batch is simply visited in more pieces.
             rows_per_step = buffer.n_rollout_threads * buffer.num_agents
-            hidden = self.policy.actor.hidden_size
-            max_steps = max(1, (2 ** 31 - 1) // max(1, rows_per_step * hidden))
+            width = self.policy.actor.hidden_size
+            if not getattr(buffer, "structured", False):
+                # dense first layers: the regenerated observation chunk [rows, D] (and the critic's input, [rows / N, N D] =
+                # the same element count, or N x that when the critic is not de-duplicated) is the widest tensor of a chunk
+                # (c5 shard: D = 5186, 65,536 rows per step -> the default 10 steps would be 3.4e9 elements, 13.6 GB)
+                width = max(width, buffer.obs_dim, buffer.share_obs_dim if not self.dedup_critic else 0)
+            max_steps = max(1, (2 ** 31 - 1) // max(1, rows_per_step * width))
             if self.update_chunk_steps > max_steps:
                 self.update_chunk_steps = max_steps
             if getattr(buffer, "structured", False):
@@ -437,8 +442,20 @@ class _Opaque(object):
 
 
 class _CheckpointUnpickler(pickle.Unpickler):
+    """Unpickler for `agent.pkl`.  The reference pickles its whole MAPPOPolicy object (mappo.py:237-240), which drags in
+    classes that do not exist here and carry no parameters -- gym spaces, argparse / omegaconf containers, whatever the
+    writing script defined in its __main__: those become `_Opaque`.  A class of the reference's OWN packages or of
+    torch (algos.* / buffer.* / utils.* / envs.* / torch.*) that cannot be resolved is a network component this package
+    does not build (the CNN base, PopArt, ...) or a genuine import bug: that error is re-raised with the class named
+    instead of surfacing later as an unrelated AttributeError inside state_dict().
+    Like the reference's `pickle.load`, this executes what the file says: load checkpoints you trust only."""
+    _MUST_RESOLVE = ("algos", "buffer", "utils", "envs", "torch", "learner")
+
     def find_class(self, module, name):
         try:
             return super().find_class(module, name)
-        except (ImportError, AttributeError):
-            return _Opaque
+        except (ImportError, AttributeError) as e:
+            if not any(module == m or module.startswith(m + ".") for m in self._MUST_RESOLVE):
+                return _Opaque
+            raise pickle.UnpicklingError("agent.pkl refers to %s.%s, which this package does not provide (%s); only the MLP / GRU "
+                                         "policies of the reference's shipped configuration can be loaded" % (module, name, e)) from e

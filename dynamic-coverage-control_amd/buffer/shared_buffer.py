@@ -18,10 +18,102 @@ shapes, but:
     CURRENT step's observations for the policy forward, and `chunk_sample` regenerates the observations of a
     range of steps with dcc_obs_expand (bit-identical) for the chunked PPO update.
 """
+import warnings
+
+import numpy as np
 import torch
 
 import utils.pytorch_utils as ptu
 from utils.util import get_shape_from_act_space, get_shape_from_obs_space
+
+
+class _RowTensor(torch.Tensor):
+    """`buffer.obs` where the rows are stored: a plain tensor whose item assignment also takes what the reference's
+    learner assigns (numpy arrays, host tensors, learner.py:224-225).  Results of operations on it are ordinary tensors."""
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    def __setitem__(self, idx, value):
+        if isinstance(value, np.ndarray):
+            value = torch.from_numpy(np.ascontiguousarray(value))
+        if torch.is_tensor(value):
+            value = value.to(device=self.device, dtype=self.dtype)
+        torch.Tensor.__setitem__(self, idx, value)
+
+
+class _Rows(object):
+    """`buffer.obs` of a state-only (compact) buffer and `buffer.share_obs` of every buffer: the reference's attribute
+    names (uav_dcc_control/learner.py:224-225 writes `share_obs[0]` / `obs[0]`, :233-234 reads `share_obs[step]` /
+    `obs[step]`, :280 `share_obs[-1]`) where no [T+1, E, N, .] tensor backs them.
+      * READ  `obs[t]` -> [E, N, D], `share_obs[t]` -> [E, N, S] (an expanded view, no memory), slices `[t0:t1]`, tuples
+        `[t, e]`.  State-only buffer: the rows are regenerated from the stored env state (dcc_obs_expand, bit-identical
+        to what the env kernel would have written) into a fresh tensor per access.
+      * WRITE `obs[t] = rows` on a state-only buffer: rows handed in from outside have no state behind them, so the
+        buffer switches to row storage on the spot (`SharedReplayBuffer.materialize_rows`, one warning) -- a learner
+        written against the reference's buffer keeps working with the shipped `compact_obs: true`.  `share_obs[t] = x`
+        is accepted and dropped when the centralised observation is the concatenation of the agents' rows (it is then a
+        view of `obs`, which the same caller writes next); a distinct centralised observation is stored.
+    Everything else (`shape`, `reshape`, `numpy`, ...) is forwarded to the full tensor / view where one exists."""
+
+    def __init__(self, buf, shared):
+        self._buf, self._shared = buf, shared
+
+    @property
+    def shape(self):
+        b = self._buf
+        return torch.Size((b.episode_length + 1, b.n_rollout_threads, b.num_agents, b.share_obs_dim if self._shared else b.obs_dim))
+
+    def __len__(self):
+        return self._buf.episode_length + 1
+
+    def _full(self):
+        b = self._buf
+        if b.compact:
+            raise RuntimeError("state-only buffer: index a step (buffer.%s[t]) or a slice of steps; the whole [T+1,E,N,.] array "
+                               "is not resident (compact_obs: false keeps it)" % ("share_obs" if self._shared else "obs"))
+        return b.share_obs_env.unsqueeze(2).expand(-1, -1, b.num_agents, -1) if self._shared else b.obs
+
+    def _steps(self, t0, t1):
+        """[t1-t0, E, N, D|S] rows of slots t0..t1-1"""
+        b = self._buf
+        if not b.compact:
+            return self._full()[t0:t1]
+        E, N, D = b.n_rollout_threads, b.num_agents, b.obs_dim
+        rows = b.expand_rows(t0, t1, torch.empty((t1 - t0) * E, N, D, dtype=torch.float32, device=b.device)).view(t1 - t0, E, N, D)
+        return rows.view(t1 - t0, E, 1, N * D).expand(-1, -1, N, -1) if self._shared else rows
+
+    def __getitem__(self, idx):
+        rest = ()
+        if isinstance(idx, tuple):
+            idx, rest = idx[0], idx[1:]
+        T1 = self._buf.episode_length + 1
+        if isinstance(idx, slice):
+            t0, t1, st = idx.indices(T1)
+            if st != 1:
+                raise IndexError("step slices of buffer rows must be contiguous")
+            out = self._steps(t0, max(t0, t1))
+            return out[(slice(None),) + rest] if rest else out
+        if torch.is_tensor(idx) and idx.dim() > 0 or isinstance(idx, (list, np.ndarray)):
+            return self._full()[(idx,) + rest]
+        t = int(idx)
+        t = t + T1 if t < 0 else t
+        if not 0 <= t < T1:
+            raise IndexError("step %d out of range" % int(idx))
+        out = self._steps(t, t + 1)[0]
+        return out[rest] if rest else out
+
+    def __setitem__(self, idx, value):
+        b = self._buf
+        if b.compact:
+            b.materialize_rows()
+        if not self._shared:
+            b.obs[idx] = b._t(value)
+        elif b._share_obs is not None:          # a centralised observation that is not the concatenation: [.., E, N, S] -> [.., E, S]
+            v = b._t(value)
+            b._share_obs[idx] = v[..., 0, :] if v.dim() >= 3 and v.shape[-2] == b.num_agents else v
+        # else: share_obs is a view of obs; the rows written to `obs` carry it
+
+    def __getattr__(self, name):
+        return getattr(self._full(), name)
 
 
 class SharedReplayBuffer(object):
@@ -60,12 +152,12 @@ class SharedReplayBuffer(object):
             self.state_energy = z(T + 1, E, n_pois)
             self.state_done = torch.zeros(T + 1, E, n_pois, dtype=torch.uint8, device=self.device)
         if self.compact:
-            self.obs = None
+            self.obs = _Rows(self, shared=False)   # lazy: rows regenerated from state on read; a row WRITE materialises storage
             self.obs_cur = z(E, N, D)         # observations of the newest slot only
             self._cur_slot = -1
             self._chunk_obs = None
         else:
-            self.obs = z(T + 1, E, N, D)
+            self.obs = z(T + 1, E, N, D).as_subclass(_RowTensor)
         self._share_obs = None if (self._shared_is_view or self.compact) else z(T + 1, E, S)
         self.value_preds = z(T + 1, E, N, 1)
         self.returns = z(T + 1, E, N, 1)
@@ -156,6 +248,14 @@ class SharedReplayBuffer(object):
         """Mark the cached per-chunk features stale (call whenever the state slots are about to be rewritten)."""
         self._feat_valid.clear()
 
+    def expand_rows(self, t0, t1, out):
+        """Observation rows of slots t0..t1-1 regenerated from the stored state into `out` [(t1-t0)*E, N, D]."""
+        N = self.num_agents
+        n = (t1 - t0) * self.n_rollout_threads
+        self._expand(self.state_pos[t0:t1].reshape(n, N, 2), self.state_vel[t0:t1].reshape(n, N, 2),
+                     self.state_energy[t0:t1].reshape(n, -1), self.state_done[t0:t1].reshape(n, -1), out)
+        return out
+
     def obs_rows(self, t0, t1):
         """[(t1-t0), E, N, D] observations of slots t0..t1-1; compact: regenerated from state into a reused chunk."""
         if not self.compact:
@@ -164,10 +264,30 @@ class SharedReplayBuffer(object):
         n = (t1 - t0) * E
         if self._chunk_obs is None or self._chunk_obs.shape[0] < n:
             self._chunk_obs = torch.empty(n, N, D, dtype=torch.float32, device=self.device)
-        out = self._chunk_obs[:n]
-        self._expand(self.state_pos[t0:t1].reshape(n, N, 2), self.state_vel[t0:t1].reshape(n, N, 2),
-                     self.state_energy[t0:t1].reshape(n, -1), self.state_done[t0:t1].reshape(n, -1), out)
-        return out.view(t1 - t0, E, N, D)
+        return self.expand_rows(t0, t1, self._chunk_obs[:n]).view(t1 - t0, E, N, D)
+
+    def materialize_rows(self):
+        """State-only -> row storage, in place: allocate `obs [T+1,E,N,D]`, fill it from the stored state, and from now on
+        behave like `compact_obs: false` with dense policy inputs (the rows written from outside have no env state behind
+        them, so neither the state slots nor the features derived from them can stand for those rows).  Triggered by
+        the first row WRITE through the reference's buffer API (`obs[t] = rows`, `insert(share_obs, obs, ...)`)."""
+        if not self.compact:
+            return
+        warnings.warn("SharedReplayBuffer: observation rows were written into a state-only buffer (compact_obs: true); switching "
+                      "to row storage [T+1,E,N,D] -- set compact_obs: false / structured_input: false to start that way")
+        T, E, N, D = self.episode_length, self.n_rollout_threads, self.num_agents, self.obs_dim
+        obs = torch.zeros(T + 1, E, N, D, dtype=torch.float32, device=self.device)
+        step = max(1, (1 << 28) // max(1, E * N * D))
+        for t0 in range(0, T + 1, step):
+            t1 = min(T + 1, t0 + step)
+            self.expand_rows(t0, t1, obs[t0:t1].view((t1 - t0) * E, N, D))
+        if 0 <= self._cur_slot <= T:
+            obs[self._cur_slot].copy_(self.obs_cur)
+        self.obs = obs.as_subclass(_RowTensor)
+        self.compact = self.structured = self.store_state = False
+        self._featurize = None
+        self._chunk_obs = None
+        self._feat_cache, self._feat_valid = {}, set()
 
     def chunk_sample(self, advantages, t0, t1, dedup_critic=False):
         """The rows of steps t0..t1-1 as the reference's 12-tuple (shared_buffer.py:258-279), for the chunked
@@ -201,9 +321,9 @@ class SharedReplayBuffer(object):
 
     @property
     def share_obs(self):
-        """[T+1, E, N, S] expanded view with the reference's shape (no memory)."""
-        so = self.share_obs_env
-        return so.unsqueeze(2).expand(-1, -1, self.num_agents, -1)
+        """[T+1, E, N, S] with the reference's shape and no memory: reads are expanded views (state-only buffer:
+        regenerated per step), writes go where `_Rows` says."""
+        return _Rows(self, shared=True)
 
     # ---- writing -----------------------------------------------------------------------------------------
     def _t(self, x):
@@ -213,6 +333,8 @@ class SharedReplayBuffer(object):
                rewards, masks, bad_masks=None, active_masks=None, available_actions=None):
         """shared_buffer.py:72-105.  `obs` may be None when the env kernel already wrote obs[step+1]."""
         s = self.step
+        if obs is not None and self.compact:     # rows from outside (a learner written against the reference's buffer)
+            self.materialize_rows()
         if obs is not None:
             dst = self.obs_slot(s + 1)
             dst.copy_(self._t(obs).view_as(dst))

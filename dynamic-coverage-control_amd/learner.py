@@ -56,6 +56,12 @@ class Learner:
         utl.seed(self.cfg.seed + self.rank)
         # measured-fastest library GEMM per listed shape instead of the library heuristic's pick (lookup only)
         self.tuned_gemms = ptu.use_tuned_gemms() if getattr(self.cfg, "tuned_gemms", True) else 0
+        if (getattr(self.cfg, "tuned_gemms", True) and self.tuned_gemms == 0 and ptu.device.type == "cuda" and self.rank == 0
+                and os.environ.get("DCC_TUNED_GEMMS", "1") != "0" and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ):
+            import warnings
+            warnings.warn("tuned_gemms: 0 entries of config/gemm_tunings_gfx950.csv match this installation (torch / ROCm / rocBLAS / "
+                          "hipBLASLt versions or GPU arch differ from the file's validators): the library heuristic picks the GEMM "
+                          "kernels (c3: about 6 % slower); tools/tune_gemms.sh regenerates the table")
 
         # 1. env (global n_rollout_threads is sharded over ranks inside make_env)
         self.train_envs = make_env(cfg=copy.deepcopy(self.cfg))
@@ -366,14 +372,22 @@ class Learner:
               "ranks": ranks}
         torch.save(ck, path)
 
-    def load_checkpoint(self, path):
+    def load_checkpoint(self, path, strict_world=None):
         """Every rank reads the file and takes ITS OWN RNG streams and env shard (the replicated parts -- parameters,
-        optimizer moments, ValueNorm, counters -- are identical on all ranks by construction)."""
+        optimizer moments, ValueNorm, counters -- are identical on all ranks by construction).
+        A checkpoint written by a different number of ranks still carries everything that does NOT depend on the rank
+        count: it is loaded (e.g. to evaluate on one GPU a model trained on eight, or to continue on another node size)
+        with a warning; only the per-rank RNG streams and env-shard states are skipped -- the run then continues from this
+        process's own seed and from reset envs (every rollout starts with a reset anyway, Q9).  strict_world=True (cfg key
+        `resume_strict`) asks for the bit-exact continuation and raises instead."""
         ck = torch.load(path, map_location="cpu", weights_only=False)
         if ck.get("format", 1) == 1:        # single-rank layout of the first format
             ck["ranks"] = [{k: ck[k] for k in ("rng_torch", "rng_numpy", "rng_cuda", "env_state")}]
             ck["world_size"] = 1
-        if ck["world_size"] != self.world:
+        if strict_world is None:
+            strict_world = bool(getattr(self.cfg, "resume_strict", False))
+        same_world = ck["world_size"] == self.world and ck["ranks"][self.rank]["env_state"]["pos"].shape[0] == self.train_envs.n_envs
+        if not same_world and strict_world:
             raise ValueError("checkpoint written by %d ranks, this job has %d (the env shards and RNG streams are per rank)"
                              % (ck["world_size"], self.world))
         self.policy.actor.load_state_dict(ck["actor"]); self.policy.critic.load_state_dict(ck["critic"])
@@ -381,11 +395,17 @@ class Learner:
         self.policy.critic_optimizer.load_state_dict(ck["critic_optimizer"])
         if ck["value_normalizer"] is not None and self.trainer.value_normalizer is not None:
             self.trainer.value_normalizer.load_state_dict(ck["value_normalizer"])
-        mine = ck["ranks"][self.rank]
-        torch.set_rng_state(mine["rng_torch"]); np.random.set_state(mine["rng_numpy"])
-        if mine["rng_cuda"] is not None and ptu.device.type == "cuda":
-            torch.cuda.set_rng_state(mine["rng_cuda"], ptu.device)
-        self.train_envs.env.set_state(**mine["env_state"])
+        if same_world:
+            mine = ck["ranks"][self.rank]
+            torch.set_rng_state(mine["rng_torch"]); np.random.set_state(mine["rng_numpy"])
+            if mine["rng_cuda"] is not None and ptu.device.type == "cuda":
+                torch.cuda.set_rng_state(mine["rng_cuda"], ptu.device)
+            self.train_envs.env.set_state(**mine["env_state"])
+        elif self.rank == 0:
+            import warnings
+            warnings.warn("checkpoint %s was written by %d rank(s) with %d envs each; this job has %d rank(s) with %d: parameters, "
+                          "optimizer moments, ValueNorm and counters are restored, the per-rank RNG streams and env states are not"
+                          % (path, ck["world_size"], ck["ranks"][0]["env_state"]["pos"].shape[0], self.world, self.train_envs.n_envs))
         self.cur_iter, self.start_iter = ck["iter"], ck["iter"] + 1
         self.total_env_steps = ck["total_env_steps"]
         from algos.algo_utils.structured import invalidate_folded_weights
@@ -395,8 +415,11 @@ class Learner:
     @torch.no_grad()
     def evaluate(self, envs=None, steps=None, deterministic=False, dump_path=None):
         """Roll the current policy without learning and report the metrics of the reference's README curves
-        (coverage rate, steps needed to cover every PoI).  `dump_path` gets the trajectory (positions,
-        PoI energies, rewards, flags per step) as an .npz -- the headless stand-in for the pyglet viewer.
+        (coverage rate, steps needed to cover every PoI).  `dump_path` gets the trajectory as an .npz -- the headless
+        stand-in for the pyglet viewer: per step the ACTIONS fed to the env and what they led to (post-step, post-auto-reset
+        positions / velocities / PoI energies / PoI done flags, reward, env-done, coverage, connect, connect_s), plus the PoI
+        table and the env constants, i.e. everything needed to replay the file through an independent implementation of the
+        env (tests/test_learner_hip.py replays it through the oracle).
         Actions are SAMPLED by default, like the reference's test / render rollouts (learner.py:143-149 run the same
         `collect` as training); deterministic=True plays the distribution's mean instead.  The two differ a lot for this
         task: the policy trained for 1500 iterations on the shipped scenario covers every PoI in 44 steps when sampled
@@ -406,7 +429,7 @@ class Learner:
         E, N = envs.n_envs, self.n_agents
         self.trainer.prep_rollout()
         obs = envs.reset_device()
-        rec = {k: [] for k in ("pos", "energy", "reward", "done", "coverage", "connect")}
+        rec = {k: [] for k in ("actions", "pos", "vel", "energy", "poi_done", "reward", "done", "coverage", "connect", "connect_s")}
         first_done = torch.full((E,), -1, dtype=torch.int32, device=ptu.device)
         cov_max = torch.zeros(E, device=ptu.device)
         rnn = masks = None
@@ -415,7 +438,8 @@ class Learner:
             masks = torch.ones(E * N, 1, device=ptu.device)
         for t in range(T):
             actions, _, rnn = self.policy.actor(obs.view(E * N, -1), rnn, masks, deterministic=deterministic)
-            out = envs.step_device(actions.view(E, N, -1).contiguous())
+            actions = actions.view(E, N, -1).contiguous()
+            out = envs.step_device(actions)
             obs = out["obs"]
             if self.recurrent:
                 masks = (1.0 - out["done"].float()).view(E, 1).expand(E, N).reshape(E * N, 1)
@@ -424,14 +448,18 @@ class Learner:
             first_done = torch.where(full, torch.full_like(first_done, t + 1), first_done)
             if dump_path is not None:
                 st = envs.env.get_state()
-                rec["pos"].append(st["pos"].cpu()); rec["energy"].append(st["energy"].cpu())
-                for k in ("reward", "done", "coverage", "connect"):
+                rec["actions"].append(actions.cpu())
+                rec["pos"].append(st["pos"].cpu()); rec["vel"].append(st["vel"].cpu())
+                rec["energy"].append(st["energy"].cpu()); rec["poi_done"].append(st["done"].cpu())
+                for k in ("reward", "done", "coverage", "connect", "connect_s"):
                     rec[k].append(out[k].cpu())
         solved = first_done > 0
         res = {"coverage_rate": float(cov_max.mean()), "solved_fraction": float(solved.float().mean()),
                "steps_to_cover": float(first_done[solved].float().mean()) if bool(solved.any()) else float("nan")}
         if dump_path is not None:
-            np.savez_compressed(dump_path, poi=envs.env.poi, **{k: torch.stack(v).numpy() for k, v in rec.items()})
+            c = self.cfg
+            np.savez_compressed(dump_path, poi=envs.env.poi, r_cover=c.r_cover, r_comm=c.r_comm, comm_r_scale=c.comm_r_scale,
+                                comm_force_scale=c.comm_force_scale, **{k: torch.stack(v).numpy() for k, v in rec.items()})
         return res
 
     def load_model(self, load_path):

@@ -38,6 +38,9 @@ def _check_line(d, steps, warmup, L=32, E=4096, world=1):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["launches_timed"] == steps * L and 0.3 < r["frac"] < 1.0 and r["bytes_per_env_step"] == 11851
     assert r["traffic"] is None or "offline" in r["traffic_source"]
+    if r["traffic"]:       # the physical fraction (counter bytes / launch time / peak) is printed beside the algorithmic one
+        assert abs(r["frac_physical"] - r["traffic"] / (r["launch_ms_avg"] * 1e-3) / 1e9 / r["peak"]) < 1e-9 and r["frac_physical"] < r["frac"]
+    assert "PASSES" in d["config"]["steps_unit"]
     # the event-timed launches fill the wall-clock region: the kernel time is the measurement, not launch gaps
     assert r["launch_ms_avg"] * steps * L <= d["ms_per_step"] * steps * 1.001
     assert r["launch_ms_avg"] * steps * L >= d["ms_per_step"] * steps * 0.9
@@ -52,11 +55,17 @@ def test_the_drivers_exact_command_is_a_real_measurement():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e5 and "sample" in c
     assert d["value"] > 50e6                          # the north-star floor, by a wide margin
+    assert "rccl" not in d and "c2_strong" not in d          # single process: no process group, strong == weak
     c4 = d["c4"]
     assert "error" not in c4, c4
     assert c4["scaling"] == "strong" and c4["envs_per_gpu"] == 8192 and c4["value"] > 1e8 and 0.3 < c4["roofline"]["frac"] < 1.0
     c5 = d["c5"]
     assert "error" not in c5, c5
+    for leg, floor in ((c4, 2e4), (c5, 2e3)):       # the CPU restatement timed at each leg's own (N, M)
+        cb = leg["cpu_baseline"]
+        assert "error" not in cb, cb
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > floor and cb["value_1core"] > floor / 4 and "sample" in cb
+    assert "tuned_gemm_entries" in d["c3"] and (d["c3"]["tuned_gemm_entries"] > 0) == (d["c3"]["tuned_gemm_warning"] is None)
     assert c5["envs_per_gpu"] == 16384 and "pull force on" in c5["workload"] and c5["value"] > 5e7 and 0.3 < c5["roofline"]["frac"] < 1.0
     c3 = d["c3"]
     assert "error" not in c3, c3
@@ -88,6 +97,14 @@ def test_gpus_2_launches_itself():
     assert "error" not in d["c3"], d["c3"]
     assert "error" not in d["c4"] and d["c4"]["envs_per_gpu"] == 4096 and d["c4"]["n_gpus"] == 2, d["c4"]
     assert d["c3"]["n_gpus"] == 2 and d["c3"]["grad_allreduce"].endswith(" x2")
+    # the N>1 line proves the job it ran as: every rank's identity gathered, an all-reduce of ones == rank count, and the
+    # fixed-4096-env (strong) c2 figure next to the weak headline
+    rc = d["rccl"]
+    assert rc["world_size"] == 2 and rc["backend"] == "gloo" and rc["allreduce_ok"] and rc["allreduce_of_ones"] == 2.0
+    assert sorted(x["rank"] for x in rc["ranks_seen"]) == [0, 1] and len({x["pid"] for x in rc["ranks_seen"]}) == 2
+    cs = d["c2_strong"]
+    assert "error" not in cs, cs
+    assert cs["scaling"] == "strong" and cs["envs_per_gpu"] == 2048 and cs["n_gpus"] == 2 and cs["roofline"]["bytes_per_env_step"] == 11851 - 64
 
 
 def test_two_ranks_under_the_drivers_launcher():

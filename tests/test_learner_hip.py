@@ -165,18 +165,153 @@ def test_checkpoint_resume_is_bit_faithful(tmp_path):
     ptu.set_gpu_mode(False)
 
 
-def test_headless_evaluation_dump(tmp_path):
+def test_checkpoint_of_another_job_size_loads_the_replicated_state(tmp_path):
+    """Advisor finding (r02): a checkpoint written by a job of another size (rank count / envs per rank) still carries
+    everything that does not depend on it.  It loads with a warning -- parameters, Adam moments, ValueNorm, counters -- and
+    the run continues; `resume_strict` keeps the old refusal."""
     import utils.pytorch_utils as ptu
     ptu.set_gpu_mode(True, 0)
     from learner import Learner
-    lr = Learner(_cfg(n_rollout_threads=8, n_eval_rollout_threads=8, num_agents=4, num_pois=16, max_ep_len=25, n_iters=1,
-                      ppo_epoch=1, algo_hidden_size=32, save_model=False))
+    kw = dict(n_eval_rollout_threads=0, num_agents=4, num_pois=16, max_ep_len=10, n_iters=3, ppo_epoch=2, algo_hidden_size=32,
+              save_model=False)
+    a = Learner(_cfg(n_rollout_threads=16, **kw))
+    a.cur_iter = 1
+    a.rollout(a.rl_buffer, a.train_envs); a.rl_update()
+    ck = str(tmp_path / "resume.pt")
+    a.save_checkpoint(ck)
+    b = Learner(_cfg(n_rollout_threads=8, seed=5, **kw))
+    with pytest.warns(UserWarning, match="per-rank RNG streams and env states are not"):
+        b.load_checkpoint(ck)
+    assert b.start_iter == 2 and b.total_env_steps == a.total_env_steps
+    for (ka, va), (kb, vb) in zip(a.policy.actor.state_dict().items(), b.policy.actor.state_dict().items()):
+        assert torch.equal(va, vb), ka
+    assert torch.equal(a.policy.critic_optimizer.exp_avg_sq, b.policy.critic_optimizer.exp_avg_sq)
+    assert torch.equal(a.trainer.value_normalizer.running_mean, b.trainer.value_normalizer.running_mean)
+    res = b.evaluate()                                   # e.g. evaluating on one GPU what eight trained
+    assert 0.0 <= res["coverage_rate"] <= 1.0
+    b.rollout(b.rl_buffer, b.train_envs); info = b.rl_update()
+    assert all(np.isfinite(v) for v in info.values())
+    c = Learner(_cfg(n_rollout_threads=8, resume_strict=True, **kw))
+    with pytest.raises(ValueError):
+        c.load_checkpoint(ck)
+    ptu.set_gpu_mode(False)
+
+
+@pytest.mark.parametrize("force", [0.0, 0.5])
+def test_headless_evaluation_dump_replays_through_the_oracle(tmp_path, force, oracle_mod):
+    """Learner.evaluate(dump_path) (reference learner.py:143-149 test rollout, :196-210 viewer): the
+    dumped trajectory is replayed through the oracle -- the ACTIONS of the file fed to an OracleEnv built from the file's own
+    constants must reproduce every dumped array: env-done / connect / connect_s / PoI-done masks and PoI energies bit for
+    bit, positions and velocities to 1e-9 (bit-identical with the pull force off), rewards and coverage to 1e-5.  The
+    metrics evaluate() returns are recomputed from the file."""
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    T, E, N, M = 40, 8, 4, 16
+    lr = Learner(_cfg(n_rollout_threads=8, n_eval_rollout_threads=E, num_agents=N, num_pois=M, max_ep_len=T, n_iters=1,
+                      ppo_epoch=1, algo_hidden_size=32, save_model=False, comm_force_scale=force, r_comm=0.4 if force == 0 else 0.15))
+    with torch.no_grad():       # a larger action noise, so that UAVs separate, cover PoIs and (force on) lose connectivity
+        lr.policy.actor.act.action_out.logstd._bias.fill_(0.7)
     path = str(tmp_path / "traj.npz")
     res = lr.evaluate(dump_path=path)
-    assert 0.0 <= res["coverage_rate"] <= 1.0 and 0.0 <= res["solved_fraction"] <= 1.0
     z = np.load(path)
-    assert z["pos"].shape == (25, 8, 4, 2) and z["energy"].shape == (25, 8, 16) and z["poi"].shape == (16, 2)
-    assert z["reward"].shape == (25, 8) and np.isfinite(z["reward"]).all()
+    assert z["pos"].shape == (T, E, N, 2) and z["vel"].shape == (T, E, N, 2) and z["actions"].shape == (T, E, N, 2)
+    assert z["energy"].shape == (T, E, M) and z["poi_done"].shape == (T, E, M) and z["poi"].shape == (M, 2)
+    assert z["actions"].dtype == np.float32
+    orc = oracle_mod.OracleEnv(E, N, M, z["poi"], float(z["r_cover"]), float(z["r_comm"]), float(z["comm_r_scale"]),
+                               float(z["comm_force_scale"]))
+    orc.reset()
+    for t in range(T):
+        ref = orc.step(z["actions"][t], want_obs=False)
+        st = orc.get_state()                                    # post-auto-reset, like the dump
+        for k in ("done", "connect", "connect_s"):
+            assert np.array_equal(z[k][t], ref[k]), (k, t)
+        assert np.array_equal(z["poi_done"][t], st["done"]), t
+        assert np.array_equal(z["energy"][t], st["energy"].astype(np.float32)), t
+        if force == 0:
+            assert np.array_equal(z["pos"][t], st["pos"]) and np.array_equal(z["vel"][t], st["vel"]), t
+        else:
+            np.testing.assert_allclose(z["pos"][t], st["pos"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(z["vel"][t], st["vel"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(z["reward"][t], ref["reward"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(z["coverage"][t], ref["coverage"], rtol=0, atol=1e-6)
+    assert z["poi_done"].any() and (z["energy"] > 0).any()       # the trajectory does something
+    if force > 0:
+        assert (z["connect_s"] == 0).any()                         # ... including the branchy force path
+    # the returned metrics are functions of the dumped arrays
+    cov = z["coverage"]
+    np.testing.assert_allclose(res["coverage_rate"], cov.max(0).mean(), rtol=1e-6)
+    full = cov >= 1.0
+    solved = full.any(0)
+    assert abs(res["solved_fraction"] - solved.mean()) < 1e-6
+    if solved.any():
+        np.testing.assert_allclose(res["steps_to_cover"], (full.argmax(0)[solved] + 1).mean(), rtol=1e-6)
+    ptu.set_gpu_mode(False)
+
+
+def test_reference_buffer_attribute_names_in_the_shipped_default_config(oracle_mod):
+    """SURVEY.md 8b B3 with the shipped YAMLs (compact_obs: true, structured_input: true).
+    (1) After a native rollout `buffer.obs[t]` / `buffer.share_obs[t]` -- the names the reference's learner reads
+        (learner.py:233-234,280) -- return the rows of every slot although none is stored: checked against the ORACLE
+        replaying the buffer's actions.
+    (2) A learner written against the reference's buffer (warmup writes share_obs[0] / obs[0], learner.py:224-225; collect
+        reads share_obs[step] / obs[step]; insert(share_obs, obs, ...) with host rows, :254-276; compute reads share_obs[-1],
+        :280; trainer.train(buffer)) runs on the same default config: the first row write switches the buffer to row
+        storage."""
+    import warnings
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    T, E, N, M = 8, 8, 4, 16
+    lr = Learner(_cfg(n_rollout_threads=E, n_eval_rollout_threads=0, num_agents=N, num_pois=M, max_ep_len=T, n_iters=1,
+                      ppo_epoch=2, algo_hidden_size=32, save_model=False))
+    buf, envs, tr = lr.rl_buffer, lr.train_envs, lr.trainer
+    assert buf.compact and buf.structured and not torch.is_tensor(buf.obs)
+    lr.rollout(buf, envs)
+    D = envs.obs_dim
+    assert tuple(buf.obs.shape) == (T + 1, E, N, D) and tuple(buf.share_obs.shape) == (T + 1, E, N, N * D)
+    c = lr.cfg
+    orc = oracle_mod.OracleEnv(E, N, M, envs.poi_xy, c.r_cover, c.r_comm, c.comm_r_scale, c.comm_force_scale)
+    rows = orc.reset().astype(np.float32)
+    for t in range(T + 1):
+        got = buf.obs[t]
+        assert got.is_cuda and tuple(got.shape) == (E, N, D)
+        assert np.array_equal(got.cpu().numpy(), rows), t                    # force off: bit-identical to the reference's rows
+        so = buf.share_obs[t]
+        assert tuple(so.shape) == (E, N, N * D) and np.array_equal(so[:, 2].cpu().numpy(), rows.reshape(E, N * D))
+        if t < T:
+            rows = orc.step(buf.actions[t].cpu().numpy())["obs"].astype(np.float32)
+    assert np.array_equal(buf.share_obs[-1][:, 0].cpu().numpy(), rows.reshape(E, N * D))
+    assert buf.compact                                                       # reads do not change the storage
+
+    # (2) the reference learner's call sequence, host rows in
+    obs = envs.reset()
+    share = np.expand_dims(obs.reshape(E, -1), 1).repeat(N, axis=1)
+    with pytest.warns(UserWarning, match="switching to row storage"):
+        buf.share_obs[0] = share.copy()
+        buf.obs[0] = obs.copy()
+    assert not buf.compact and torch.is_tensor(buf.obs) and np.array_equal(buf.obs[0].cpu().numpy(), obs)
+    buf.step = 0
+    for step in range(T):
+        tr.prep_rollout()
+        with torch.no_grad():
+            value, action, logp, _, _ = tr.policy.get_actions(buf.share_obs[step].reshape(E * N, -1), buf.obs[step].reshape(E * N, -1),
+                                                              None, None, buf.masks[step].reshape(E * N, 1))
+        actions = action.view(E, N, 2).cpu().numpy()
+        obs, rewards, dones, infos = envs.step(actions.copy())
+        masks = np.ones((E, N, 1), np.float32); masks[dones] = 0.0
+        share = np.expand_dims(obs.reshape(E, -1), 1).repeat(N, axis=1)
+        buf.insert(share, obs, None, None, actions, logp.view(E, N, 1).cpu().numpy(), value.view(E, N, 1).cpu().numpy(), rewards, masks)
+        assert np.array_equal(buf.obs[step + 1].cpu().numpy(), obs)
+    with torch.no_grad():
+        nv = tr.policy.get_values(buf.share_obs[-1].reshape(E * N, -1), None, buf.masks[-1].reshape(E * N, 1))
+    buf.compute_returns(nv.view(E, N, 1), tr.value_normalizer)
+    tr.prep_training()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        info = tr.train(buf, update_actor=True)
+    buf.after_update()
+    assert all(np.isfinite(v) for v in info.values()) and info["ratio"] > 0
     ptu.set_gpu_mode(False)
 
 

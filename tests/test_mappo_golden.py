@@ -37,9 +37,9 @@ def _sd(prefix):
     return {k[len(prefix):]: torch.from_numpy(Z[k]) for k in Z.files if k.startswith(prefix)}
 
 
-def _policy(cfg):
+def _policy(cfg, dev="cpu"):
     import utils.pytorch_utils as ptu
-    ptu.set_gpu_mode(False)
+    ptu.set_gpu_mode(dev == "cuda", 0)
     from algos.mappo import MAPPOPolicy, MAPPOTrainer
     pol = MAPPOPolicy(cfg, Box(D), Box(S), Box(A))
     # the reference's state_dict also holds its dead `mlp.fc_h` template: ignored
@@ -277,7 +277,7 @@ def test_compact_buffer_update_matches_reference():
     pol, tr = _policy(cfg)
     _set_vn(tr.value_normalizer, "vn0")
     buf, calls = _compact_buffer(cfg)
-    assert buf.obs is None and buf.obs_cur.shape == (E, N, D)
+    assert not torch.is_tensor(buf.obs) and buf.obs_cur.shape == (E, N, D)       # no [T+1,E,N,D] array is resident
     full = (T + 1) * E * N * D * 4
     compact = sum(a.numel() * a.element_size() for a in (buf.state_pos, buf.state_vel, buf.state_energy, buf.state_done))
     assert compact == (T + 1) * E * (32 * N + 5 * 3) and compact < full
@@ -290,6 +290,50 @@ def test_compact_buffer_update_matches_reference():
     for pre, mod in (("actor2/", pol.actor), ("critic2/", pol.critic)):
         for k, v in mod.state_dict().items():
             np.testing.assert_allclose(v.numpy(), Z[pre + k], rtol=1e-3, atol=2e-5, err_msg=pre + k)
+
+
+def test_compact_buffer_answers_the_reference_attribute_names():
+    """SURVEY.md 8b B3 in the shipped default (compact_obs: true): `buffer.obs[t]` / `buffer.share_obs[t]` as the
+    reference's learner reads them (learner.py:233-234, :280) are regenerated from the stored state; rows WRITTEN through
+    the reference's API (learner.py:224-225 `share_obs[0] = ..; obs[0] = ..`, insert(share_obs, obs, ...)) switch the
+    buffer to row storage, after which it behaves like the reference's buffer."""
+    cfg = make_cfg()
+    buf, calls = _compact_buffer(cfg)
+    ref = Z["buf_obs"]
+    assert tuple(buf.obs.shape) == (T + 1, E, N, D) and tuple(buf.share_obs.shape) == (T + 1, E, N, S) and len(buf.obs) == T + 1
+    np.testing.assert_array_equal(buf.obs[3].numpy(), ref[3])
+    np.testing.assert_array_equal(buf.obs[-1].numpy(), ref[-1])
+    np.testing.assert_array_equal(buf.obs[2:5].numpy(), ref[2:5])
+    np.testing.assert_array_equal(buf.obs[4, 1].numpy(), ref[4, 1])
+    so = buf.share_obs[5]
+    assert tuple(so.shape) == (E, N, S)
+    np.testing.assert_array_equal(so.numpy(), np.repeat(ref[5].reshape(E, 1, S), N, axis=1))
+    np.testing.assert_array_equal(np.concatenate(buf.share_obs[-1].numpy()), np.repeat(ref[-1].reshape(E, 1, S), N, axis=1).reshape(E * N, S))
+    a, b = buf.obs[1], buf.obs[2]
+    assert a.data_ptr() != b.data_ptr()                     # every read is its own tensor
+    with pytest.raises(RuntimeError):
+        buf.obs.numpy()                                     # the whole array is not resident
+    assert buf.compact and calls
+    # --- the reference's warmup: rows from outside -> row storage
+    new0 = np.random.RandomState(0).randn(E, N, D).astype(np.float32)
+    with pytest.warns(UserWarning, match="switching to row storage"):
+        buf.share_obs[0] = np.repeat(new0.reshape(E, 1, S), N, axis=1).copy()
+        buf.obs[0] = new0.copy()
+    assert not buf.compact and not buf.structured and torch.is_tensor(buf.obs) and tuple(buf.obs.shape) == (T + 1, E, N, D)
+    np.testing.assert_array_equal(buf.obs[0].numpy(), new0)
+    np.testing.assert_array_equal(buf.obs[1:].numpy(), ref[1:])                 # the other slots were filled from the state
+    np.testing.assert_array_equal(buf.share_obs[0].numpy(), np.repeat(new0.reshape(E, 1, S), N, axis=1))
+    assert buf.share_obs_env.data_ptr() == buf.obs.data_ptr() and tuple(buf.share_obs.numpy().shape) == (T + 1, E, N, S)
+    # --- the reference's insert(share_obs, obs, ...) on a fresh state-only buffer
+    buf2, _ = _compact_buffer(cfg)
+    rows = np.random.RandomState(1).randn(E, N, D).astype(np.float32)
+    z1 = np.zeros((E, N, 1), np.float32)
+    with pytest.warns(UserWarning):
+        buf2.insert(np.repeat(rows.reshape(E, 1, S), N, axis=1), rows, None, None, np.zeros((E, N, A), np.float32),
+                    np.zeros((E, N, 1), np.float32), z1, z1, np.ones((E, N, 1), np.float32))
+    np.testing.assert_array_equal(buf2.obs[1].numpy(), rows)
+    sample = next(buf2.feed_forward_generator(torch.zeros(T, E, N, 1), 1, dedup_critic=True))     # the reference's generator works now
+    assert tuple(sample[1].shape) == (T * E * N, D)
 
 
 def test_compact_buffer_slots_and_guards():
@@ -318,28 +362,45 @@ def test_compact_buffer_slots_and_guards():
     assert plain.share_obs_env_at(2).data_ptr() == plain.obs[2].data_ptr()
 
 
-def test_load_model_accepts_a_checkpoint_written_by_the_reference():
+@pytest.mark.parametrize("dev", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_load_model_accepts_a_checkpoint_written_by_the_reference(dev):
     """tests/golden/ref_agent_small/agent.pkl was written by the reference's MAPPOTrainer.save_model (a pickle of its
     MAPPOPolicy object, tools/gen_golden_ref_checkpoint.py; same seed as mappo_small.npz).  load_model takes over the
-    parameters (dropping the dead mlp.fc_h template) although classes the pickle mentions do not exist here."""
-    pol, tr = _policy(make_cfg())
+    parameters (dropping the dead mlp.fc_h template) although classes the pickle mentions do not exist here.  On the device
+    (`-m gpu`) the loaded policy then reproduces the reference's own evaluate_actions / act outputs."""
+    import utils.pytorch_utils as ptu
+    pol, tr = _policy(make_cfg(), dev)
     for p in list(pol.actor.parameters()) + list(pol.critic.parameters()):
+        assert p.device.type == dev
         p.data.add_(1.0)                                        # make sure values really come from the file
     tr.load_model(os.path.join(GOLDEN, "ref_agent_small"))
     for name, net in (("actor/", pol.actor), ("critic/", pol.critic)):
         for k, v in net.state_dict().items():
-            np.testing.assert_array_equal(v.numpy(), Z[name + k], err_msg=k)
+            assert v.device.type == dev
+            np.testing.assert_array_equal(v.cpu().numpy(), Z[name + k], err_msg=k)
     # parameters are still the views of the flat optimizer storage (the load copies in place)
     opt = pol.actor_optimizer
     assert all(p.data_ptr() == opt.flat_param.data_ptr() + 4 * off for p, off in zip(opt._params, opt._offsets))
+    # the loaded networks compute what the reference computed with these parameters (reference fixtures ev_*)
+    tr.prep_rollout()
+    t = lambda a: torch.from_numpy(a).to(ptu.device)
+    with torch.no_grad():
+        v, logp, ent = pol.evaluate_actions(t(Z["ev_sobs"]), t(Z["ev_obs"]), None, None, t(Z["ev_act"]), None, None,
+                                            torch.ones(64, 1, device=ptu.device))
+        mean_act, _ = pol.act(t(Z["ev_obs"]), deterministic=True)
+    np.testing.assert_allclose(v.cpu().numpy(), Z["ev_values"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), Z["ev_logp"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(ent), float(Z["ev_entropy"]), rtol=1e-6)
+    np.testing.assert_allclose(mean_act.cpu().numpy(), Z["ev_mean_act"], rtol=1e-5, atol=1e-7)
     # round trip through this package's own format
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         tr.save_model(d)
-        pol2, tr2 = _policy(make_cfg())
+        pol2, tr2 = _policy(make_cfg(), dev)
         pol2.actor.act.action_out.logstd._bias.data.fill_(3.0)
         tr2.load_model(d)
         assert float(pol2.actor.act.action_out.logstd._bias.abs().sum()) == 0.0
+    ptu.set_gpu_mode(False)
 
 
 def test_double_surrogate_false_uses_one_log_prob_column():
@@ -357,3 +418,91 @@ def test_double_surrogate_false_uses_one_log_prob_column():
     assert out[True][3][1] == 2 and out[False][3][1] == 1
     np.testing.assert_allclose(out[False][0], 0.5 * out[True][0], rtol=1e-6)
     assert out[False][1] == out[True][1] and out[False][2] == out[True][2]
+
+
+def test_flat_adam_reattaches_parameters_that_left_its_storage():
+    """Advisor finding (r02): kernels write parameters through raw pointers into flat_param, so a parameter whose storage was
+    moved behind the optimizer's back (module._apply / .to(), GRU.flatten_parameters, p.data = ...) must not silently keep
+    computing with a detached tensor.  zero_grad / clip_and_step compare pointers (host side), re-attach a moved parameter
+    with its current values, and raise when dtype / size changed."""
+    from algos.algo_utils.optim import FlatAdam
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(5, 3)
+    opt = FlatAdam(lin.parameters(), lr=1e-2)
+    attached = lambda: all(p.data_ptr() == opt.flat_param.data_ptr() + 4 * off for p, off in zip(opt._params, opt._offsets))
+    assert attached()
+    lin.weight.data = lin.weight.data.clone() + 1.0          # moved, with values the network now computes with
+    moved = lin.weight.data.clone()
+    assert not attached()
+    opt.zero_grad()
+    assert attached() and torch.equal(lin.weight.data, moved)
+    lin(torch.randn(4, 5)).sum().backward()
+    before = lin.weight.data.clone()
+    lin.bias.data = lin.bias.data.clone()                    # moved between backward and the step
+    opt.clip_and_step(10.0)
+    assert attached() and not torch.equal(lin.weight.data, before)       # the step reached the tensors the module uses
+    lin.weight.data = lin.weight.data.double()
+    with pytest.raises(RuntimeError, match="left the optimizer's flat storage"):
+        opt.zero_grad()
+
+
+def test_checkpoint_unpickler_only_hides_known_parameter_free_classes(tmp_path):
+    """Advisor finding (r02): a reference checkpoint mentioning gym spaces loads (those objects carry no parameters), one
+    mentioning a network class this package does not build names that class instead of failing later in state_dict()."""
+    import pickle, sys, types
+    from algos.mappo import _CheckpointUnpickler, _Opaque
+    def dump_with_fake(modname, clsname, path):
+        mod = types.ModuleType(modname)
+        cls = type(clsname, (object,), {"__module__": modname})
+        setattr(mod, clsname, cls)
+        parents = modname.split(".")
+        added = []
+        for i in range(1, len(parents) + 1):
+            name = ".".join(parents[:i])
+            if name not in sys.modules:
+                sys.modules[name] = mod if i == len(parents) else types.ModuleType(name)
+                added.append(name)
+        try:
+            if modname in sys.modules and sys.modules[modname] is not mod:
+                setattr(sys.modules[modname], clsname, cls)
+            with open(path, "wb") as f:
+                pickle.dump({"x": cls()}, f)
+        finally:
+            for name in added:
+                sys.modules.pop(name, None)
+            if modname in sys.modules and hasattr(sys.modules[modname], clsname):
+                delattr(sys.modules[modname], clsname)
+    ok, bad = str(tmp_path / "ok.pkl"), str(tmp_path / "bad.pkl")
+    dump_with_fake("gym.spaces.box", "Box", ok)
+    dump_with_fake("algos.algo_utils.cnn", "CNNBase", bad)
+    with open(ok, "rb") as f:
+        assert isinstance(_CheckpointUnpickler(f).load()["x"], _Opaque)
+    with open(bad, "rb") as f, pytest.raises(pickle.UnpicklingError, match="algos.algo_utils.cnn.CNNBase"):
+        _CheckpointUnpickler(f).load()
+
+
+def test_chunk_clamp_counts_the_widest_tensor_of_a_chunk():
+    """Advisor finding (r02): the 2^31-element guard of the chunked update must use the observation width on the dense
+    first-layer path (c5 shard: D = 5186 >> hidden), not only [rows, hidden]."""
+    cfg = make_cfg(update_chunk_steps=1000, ppo_epoch=1)
+    pol, tr = _policy(cfg)
+
+    class Stop(Exception):
+        pass
+
+    class FakeBuf:            # only what train() reads before the first epoch
+        compact, structured = True, False
+        episode_length, n_rollout_threads, num_agents = 150, 2048, 32
+        obs_dim, share_obs_dim = 5186, 32 * 5186
+        returns = value_preds = torch.zeros(151, 1, 1, 1)
+        active_masks = torch.ones(151, 1, 1, 1)
+    tr._epoch = lambda *a: (_ for _ in ()).throw(Stop())
+    with pytest.raises(Stop):
+        tr.train(FakeBuf())
+    assert tr.update_chunk_steps == (2 ** 31 - 1) // (2048 * 32 * 5186) == 6
+    FakeBuf.structured = True
+    FakeBuf.features_rows = lambda self, a, b: None
+    tr.update_chunk_steps = 1000
+    with pytest.raises(Stop):
+        tr.train(FakeBuf())
+    assert tr.update_chunk_steps == 1000          # features are narrow: [rows, hidden] = 65,536 x 32 per step, no clamp needed

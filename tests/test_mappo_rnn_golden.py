@@ -1,6 +1,7 @@
 """Recurrent MAPPO variants (reference buffer/shared_buffer.py:281-487, algos/algo_utils/rnn.py,
 r_actor_critic.py with use_recurrent_policy / use_naive_recurrent_policy) against fixtures produced by the reference
-itself (tools/gen_golden_mappo_rnn.py).  CPU torch: host-side logic; the device run is in test_learner_hip.py."""
+itself (tools/gen_golden_mappo_rnn.py).  Every test runs twice: on CPU torch (host-side logic, `-m "not gpu"`) and on the
+device (`-m gpu`: MIOpen GRU, device gathers of both generators, the fused loss / optimizer kernels in the update)."""
 import os
 
 import numpy as np
@@ -13,6 +14,7 @@ from test_mappo_golden import make_cfg, Box
 Z = np.load(os.path.join(GOLDEN, "mappo_rnn_small.npz"))
 N, E, T, D, A, H, L, MB = 3, 4, 12, 10, 2, 16, 4, 2
 S, B = N * D, E * N
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
 FIELDS = ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "returns", "masks",
           "active_masks", "old_logp", "adv")
 
@@ -27,9 +29,22 @@ def _sd(prefix):
     return {k[len(prefix):]: torch.from_numpy(Z[k]) for k in Z.files if k.startswith(prefix)}
 
 
-def _setup(mode):
+def _dev():
     import utils.pytorch_utils as ptu
-    ptu.set_gpu_mode(False)
+    return ptu.device
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _setup(mode, dev="cpu"):
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(dev == "cuda", 0)
     from algos.mappo import MAPPOPolicy, MAPPOTrainer
     from buffer.shared_buffer import SharedReplayBuffer
     cfg = _cfg(mode)
@@ -39,58 +54,62 @@ def _setup(mode):
         assert not missing and all(".fc_h." in k for k in unexpected), (missing, unexpected)
     tr = MAPPOTrainer(cfg, pol)
     buf = SharedReplayBuffer(cfg, Box(D), Box(S), Box(A))
-    buf.obs.copy_(torch.from_numpy(Z["buf_obs"]))
-    buf.actions.copy_(torch.from_numpy(Z["buf_actions"]))
-    buf.action_log_probs.copy_(torch.from_numpy(Z["buf_logp"]).expand_as(buf.action_log_probs))
-    buf.rewards.copy_(torch.from_numpy(Z["buf_rewards"]))
-    buf.value_preds.copy_(torch.from_numpy(Z["buf_value_preds"]))
-    buf.masks.copy_(torch.from_numpy(Z["buf_masks"]))
-    buf.rnn_states.copy_(torch.from_numpy(Z["buf_rnn_states"]))
-    buf.rnn_states_critic.copy_(torch.from_numpy(Z["buf_rnn_states_critic"]))
+    assert buf.obs.device.type == dev and next(pol.actor.parameters()).device.type == dev
+    buf.obs.copy_(_t(Z["buf_obs"]))
+    buf.actions.copy_(_t(Z["buf_actions"]))
+    buf.action_log_probs.copy_(_t(Z["buf_logp"]).expand_as(buf.action_log_probs))
+    buf.rewards.copy_(_t(Z["buf_rewards"]))
+    buf.value_preds.copy_(_t(Z["buf_value_preds"]))
+    buf.masks.copy_(_t(Z["buf_masks"]))
+    buf.rnn_states.copy_(_t(Z["buf_rnn_states"]))
+    buf.rnn_states_critic.copy_(_t(Z["buf_rnn_states_critic"]))
     return cfg, pol, tr, buf
 
 
+@pytest.mark.parametrize("dev", DEVICES)
 @pytest.mark.parametrize("mode", ["chunk", "naive"])
-def test_rnn_layer_sequence_and_single_step_match_reference(mode):
+def test_rnn_layer_sequence_and_single_step_match_reference(mode, dev):
     """RNNLayer: the mask-every-step formulation (no host round trip) equals the reference's segment-wise GRU calls on
     a sequence with episode ends inside; the single-step (rollout) path returns the reference's new states."""
-    cfg, pol, tr, buf = _setup(mode)
+    cfg, pol, tr, buf = _setup(mode, dev)
     assert buf.rnn_states.shape == (T + 1, E, N, 1, H)
     tr.prep_rollout()
     pre = mode + "/"
     obs, masks = Z["buf_obs"], Z["buf_masks"]
-    ev_obs = torch.from_numpy(obs[:-1].reshape(T * B, D))
+    ev_obs = _t(obs[:-1].reshape(T * B, D))
     ev_sobs = buf.share_obs[:-1].reshape(T * B, S)
     with torch.no_grad():
         v, lp, ent = pol.evaluate_actions(ev_sobs, ev_obs, buf.rnn_states[0].reshape(B, 1, H), buf.rnn_states_critic[0].reshape(B, 1, H),
-                                          torch.from_numpy(Z["buf_actions"].reshape(T * B, A)),
-                                          torch.from_numpy(masks[:-1].reshape(T * B, 1)), None, torch.ones(T * B, 1))
+                                          _t(Z["buf_actions"].reshape(T * B, A)),
+                                          _t(masks[:-1].reshape(T * B, 1)), None, torch.ones(T * B, 1, device=_dev()))
         sv, sa, _, sra, src = pol.get_actions(buf.share_obs[2].reshape(B, S), buf.obs[2].reshape(B, D),
                                               buf.rnn_states[2].reshape(B, 1, H), buf.rnn_states_critic[2].reshape(B, 1, H),
                                               buf.masks[2].reshape(B, 1), deterministic=True)
-    np.testing.assert_allclose(v.numpy(), Z[pre + "ev_values"], rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(lp.numpy(), Z[pre + "ev_logp"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(_np(v), Z[pre + "ev_values"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(_np(lp), Z[pre + "ev_logp"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(float(ent), float(Z[pre + "ev_entropy"]), rtol=1e-6)
-    np.testing.assert_allclose(sv.numpy(), Z[pre + "step_values"], rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(sa.numpy(), Z[pre + "step_actions"], rtol=1e-5, atol=1e-7)
-    np.testing.assert_allclose(sra.numpy(), Z[pre + "step_rnn_actor"], rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(src.numpy(), Z[pre + "step_rnn_critic"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(_np(sv), Z[pre + "step_values"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(_np(sa), Z[pre + "step_actions"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(_np(sra), Z[pre + "step_rnn_actor"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(_np(src), Z[pre + "step_rnn_critic"], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("dev", DEVICES)
 @pytest.mark.parametrize("mode", ["chunk", "naive"])
-def test_recurrent_generators_yield_the_reference_minibatches(mode):
+def test_recurrent_generators_yield_the_reference_minibatches(mode, dev):
     """Same seed -> same permutation -> the same mini-batches, field by field, bit for bit (they are gathers)."""
-    cfg, pol, tr, buf = _setup(mode)
+    cfg, pol, tr, buf = _setup(mode, dev)
     pre = mode + "/"
-    buf.returns.copy_(torch.from_numpy(Z[pre + "returns"]))
-    adv = torch.from_numpy(Z[pre + "adv_norm"])
+    buf.returns.copy_(_t(Z[pre + "returns"]))
+    adv = _t(Z[pre + "adv_norm"])
     torch.manual_seed(21)
     gen = buf.recurrent_generator(adv, MB, L) if mode == "chunk" else buf.naive_recurrent_generator(adv, MB)
     n = 0
     for i, sample in enumerate(gen):
         for name, arr in zip(FIELDS, sample[:11]):
             ref = Z["%sgen%d_%s" % (pre, i, name)]
-            got = arr.numpy()
+            assert arr.device.type == dev
+            got = _np(arr)
             assert got.shape == ref.shape, (name, got.shape, ref.shape)
             np.testing.assert_array_equal(got, ref, err_msg="%s minibatch %d" % (name, i))
         assert sample[11] is None
@@ -100,21 +119,22 @@ def test_recurrent_generators_yield_the_reference_minibatches(mode):
     gen2 = (buf.recurrent_generator(adv, MB, L, perm=Z[pre + "gen_perm"]) if mode == "chunk"
             else buf.naive_recurrent_generator(adv, MB, perm=Z[pre + "gen_perm"]))
     first = next(iter(gen2))
-    np.testing.assert_array_equal(first[1].numpy(), Z[pre + "gen0_obs"])
+    np.testing.assert_array_equal(_np(first[1]), Z[pre + "gen0_obs"])
 
 
+@pytest.mark.parametrize("dev", DEVICES)
 @pytest.mark.parametrize("mode", ["chunk", "naive"])
-def test_recurrent_train_reproduces_the_reference_update(mode):
+def test_recurrent_train_reproduces_the_reference_update(mode, dev):
     """MAPPOTrainer.train with the recurrent generators (2 epochs x 2 mini-batches): losses, gradient norms and the
     post-update parameters of actor / critic (GRU weights included) equal the reference's."""
-    cfg, pol, tr, buf = _setup(mode)
+    cfg, pol, tr, buf = _setup(mode, dev)
     pre = mode + "/"
     vn = tr.value_normalizer
-    vn.running_mean.copy_(torch.from_numpy(Z[pre + "vn0_mean"]))
-    vn.running_mean_sq.copy_(torch.from_numpy(Z[pre + "vn0_mean_sq"]))
-    vn.debiasing_term.copy_(torch.from_numpy(Z[pre + "vn0_debias"]))
-    buf.returns.copy_(torch.from_numpy(Z[pre + "returns"]))
-    np.testing.assert_allclose(tr.normalized_advantages(buf).numpy(), Z[pre + "adv_norm"], rtol=2e-5, atol=2e-6)
+    vn.running_mean.copy_(_t(Z[pre + "vn0_mean"]))
+    vn.running_mean_sq.copy_(_t(Z[pre + "vn0_mean_sq"]))
+    vn.debiasing_term.copy_(_t(Z[pre + "vn0_debias"]).reshape(vn.debiasing_term.shape))
+    buf.returns.copy_(_t(Z[pre + "returns"]))
+    np.testing.assert_allclose(_np(tr.normalized_advantages(buf)), Z[pre + "adv_norm"], rtol=2e-5, atol=2e-6)
     tr.prep_training()
     torch.manual_seed(3)
     info = tr.train(buf, update_actor=True)
@@ -123,7 +143,7 @@ def test_recurrent_train_reproduces_the_reference_update(mode):
     for name, net in (("actor2", pol.actor), ("critic2", pol.critic)):
         sd = net.state_dict()
         for k, v in sd.items():
-            np.testing.assert_allclose(v.numpy(), Z["%s%s/%s" % (pre, name, k)], rtol=2e-4, atol=2e-6, err_msg=k)
+            np.testing.assert_allclose(_np(v), Z["%s%s/%s" % (pre, name, k)], rtol=2e-4, atol=2e-6, err_msg=k)
     assert "rnn.rnn.weight_hh_l0" in pol.actor.state_dict() and "rnn.norm.weight" in pol.critic.state_dict()
 
 
