@@ -447,6 +447,7 @@ def main():
         poi_all = np.concatenate([poi_all, np.random.RandomState(2024).uniform(-1, 1, (M - len(poi_all), 2))])
     poi = poi_all[:M]
     env = dcc_hip.HipCoverageEnv(E, N, M, poi, r_cover, r_comm, crs, cfs, device=local_dev)
+    kernel_choice = env.kernel_choice()      # roles vs fused, measured by dcc_env_create on this box
     env.reset()
     out = env.alloc_out(T, obs=not args.no_obs, assign=not args.no_assign)
     if args.no_scalars:
@@ -532,7 +533,9 @@ def main():
     res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                        "algorithmic_bytes_per_launch": alg,
-                       "kernel": "dcc_env_roles_kernel<ACT,FORCE,NC,MC> (c2: <0,false,8,64>); DCC_NO_ROLES=1: dcc_env_kernel<1,0,false,8,64>",
+                       "kernel": ("dcc_env_kernel<1,ACT,FORCE,NC,MC> (fused: one wave per env)" if (kernel_choice["choice"] == "fused" or os.environ.get("DCC_NO_ROLES") == "1")
+                                  else "dcc_env_roles_kernel<ACT,FORCE,NC,MC> (a physics + an observation wave per two envs)") + " -- c2: <..,0,false,8,64>",
+                       "kernel_choice": kernel_choice,
                        "bytes_per_env_step": bstep, "timing": "HIP events around every timed launch on the launch stream",
                        "launch_ms_avg": avg_ms, "launch_ms_min": sms[0], "launch_ms_median": sms[len(sms) // 2],
                        "launch_ms_max": sms[-1], "launches_timed": len(ms), "frac_of_achievable_6300": ach / 6300.0,

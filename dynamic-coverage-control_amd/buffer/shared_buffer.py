@@ -142,6 +142,7 @@ class SharedReplayBuffer(object):
         self.structured = featurizer is not None
         self.store_state = self.compact or self.structured
         self._feat_cache, self._feat_valid = {}, set()
+        self._step_feats, self._step_feat_slot = None, -1
         if self.store_state:
             if not self._shared_is_view or n_pois is None or (self.compact and expander is None):
                 raise ValueError("state-storing buffer needs share_obs == concat(obs), n_pois and (compact) an expander "
@@ -218,8 +219,19 @@ class SharedReplayBuffer(object):
 
     def features_at(self, t):
         """Compact policy-input features of slot t (structured mode): dict(head [E,N,HD], poi_feat [E,2M], stats, cstats) plus
-        the per-env GEMM inputs xa / xc built from them (algo_utils/structured.py: env_gemm_inputs)."""
+        the per-env GEMM inputs xa / xc built from them (algo_utils/structured.py: env_gemm_inputs).  When the env launch that
+        produced slot t also produced its features (feature_slot / dcc_env_step_features) those are returned as they are."""
+        if self._step_feats is not None and self._step_feat_slot == t:
+            return self._step_feats[t & 1]
         return self._with_gemm_inputs(self._featurize(self.state_pos[t], self.state_vel[t], self.state_energy[t], self.state_done[t]))
+
+    def feature_slot(self, t, alloc):
+        """Destination for the features of slot t written by the env launch itself: two alternating sets (the policy reads the
+        set of slot t while the env step fills the set of slot t + 1).  `alloc()` builds one set (HipCoverageEnv.alloc_features)."""
+        if self._step_feats is None:
+            self._step_feats = [alloc(), alloc()]
+        self._step_feat_slot = t
+        return self._step_feats[t & 1]
 
     @staticmethod
     def _with_gemm_inputs(f):
@@ -247,6 +259,7 @@ class SharedReplayBuffer(object):
     def invalidate_features(self):
         """Mark the cached per-chunk features stale (call whenever the state slots are about to be rewritten)."""
         self._feat_valid.clear()
+        self._step_feat_slot = -1
 
     def expand_rows(self, t0, t1, out):
         """Observation rows of slots t0..t1-1 regenerated from the stored state into `out` [(t1-t0)*E, N, D]."""

@@ -840,49 +840,39 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v) {
     return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
-// PPL PoIs per lane, loaded ONCE into registers: the PoI coordinates / energies / done flags are re-used by every agent row
-// and both moment passes (read from global memory inside the agent loop they cost a dependent L2 round trip per agent and
-// pass: 16 at 8 UAVs, which made this kernel 30 us per 4096 states).
+// The features of ONE state held in a wave's registers: lane i < N has UAV i (mp, mv), lane l has PoIs {l, l + 64, ...}
+// (coordinates qx / qy, energy en, done bit t of dmask).  The PoI coordinates / energies / done flags are re-used by every
+// agent row and both moment passes, so they stay in registers (read from global memory inside the agent loop they cost a
+// dependent L2 round trip per agent and pass: 16 at 8 UAVs, which made the stand-alone kernel 30 us per 4096 states).
+// Shared by dcc_obs_features_kernel (state from HBM) and by the env kernels (dcc_env_step_features: the state the step just
+// produced, never re-read).  hrow: N*HD floats of per-wave LDS when p.stage, else NULL.
 template <int PPL>
-__global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatParams p) {
-    extern __shared__ __attribute__((aligned(16))) float feat_lds[];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = blockIdx.x * kWavesPerBlock + wid;
-    if (n >= p.n) return;
+__device__ __forceinline__ void produce_features(const FeatParams& p, const size_t n, const int lane, float* hrow,
+                                                 const double2 mp, const double2 mv, const double (&qx)[PPL],
+                                                 const double (&qy)[PPL], const float (&en)[PPL], const unsigned dmask) {
     const int N = p.N, M = p.M, HD = 4 + 2 * (N - 1), D = HD + 5 * M;
-    // The head values of agent i come from different lanes (own vel / pos from lane i, the relative position of UAV a from
-    // lane a): written straight to HBM they are 4-byte stores at an 8-byte stride, 4 store instructions per agent that
-    // each touch a cache line partially.  Staged per wave in LDS (N*HD floats) they leave as two float4 runs per state.
-    float* hrow = p.stage ? feat_lds + (size_t)wid * N * HD : nullptr;
-    double2 mp = make_double2(0.0, 0.0), mv = mp;
-    if (lane < N) { mp = p.pos[(size_t)n * N + lane]; mv = p.vel[(size_t)n * N + lane]; }
     // The (energy, m_energy, done) columns of a row are the same for every agent of the env: their sum and sum of squares
     // are formed ONCE per state (se, qe), and a row's moments are  mean = (sum of its own columns + se) / D,
     // m2 = sum (own - mean)^2 + (qe - 2 mean se + 3M mean^2)  -- float64 throughout, so expanding the square of the shared
     // part costs nothing measurable in accuracy (values are O(1), checked to 1e-11 against the two-pass form), and the agent
     // loop touches two columns per PoI instead of five.
-    double qx[PPL], qy[PPL];
     double se = 0.0, qe = 0.0;
     const double me = (double)p.m_energy;
 #pragma unroll
     for (int t = 0; t < PPL; ++t) {
         const int j = t * 64 + lane;
-        qx[t] = qy[t] = 0.0;
         if (j < M) {
-            const double2 q = p.poi[j];
-            const float e = p.energy[(size_t)n * M + j];
-            const float d = p.done[(size_t)n * M + j] ? 1.f : 0.f;
-            qx[t] = q.x; qy[t] = q.y;
+            const float e = en[t];
+            const float d = ((dmask >> t) & 1u) ? 1.f : 0.f;
             se += ((double)e + me) + (double)d;
             qe += ((double)e * (double)e + me * me) + (double)d * (double)d;
-            if (p.poi_feat) { float* f = p.poi_feat + (size_t)n * 2 * M; f[j] = e; f[M + j] = d; }
-            if (p.xa) { float* f = p.xa + (size_t)n * p.ka; f[j] = e; f[M + j] = d; }
-            if (p.xc) { float* f = p.xc + (size_t)n * p.kc + N * HD; f[j] = e; f[M + j] = d; }
+            if (p.poi_feat) { float* f = p.poi_feat + n * 2 * M; f[j] = e; f[M + j] = d; }
+            if (p.xa) { float* f = p.xa + n * p.ka; f[j] = e; f[M + j] = d; }
+            if (p.xc) { float* f = p.xc + n * p.kc + N * HD; f[j] = e; f[M + j] = d; }
         }
     }
-    if (p.xa) { const int c = 2 * M + lane; if (c < p.ka) p.xa[(size_t)n * p.ka + c] = lane == 0 ? 1.f : 0.f; }          // 1 | zero padding (< 8)
-    if (p.xc) { const int c = N * HD + 2 * M + lane; if (c < p.kc) p.xc[(size_t)n * p.kc + c] = lane == 0 ? 1.f : 0.f; }
+    if (p.xa) { const int c = 2 * M + lane; if (c < p.ka) p.xa[n * p.ka + c] = lane == 0 ? 1.f : 0.f; }          // 1 | zero padding (< 8)
+    if (p.xc) { const int c = N * HD + 2 * M + lane; if (c < p.kc) p.xc[n * p.kc + c] = lane == 0 ? 1.f : 0.f; }
     const bool want_stats = p.stats || p.cstats;
     if (want_stats) { se = wave_sum_f64_dpp(se); qe = wave_sum_f64_dpp(qe); }
     double my_mean = 0.0, my_m2 = 0.0;     // lane i keeps the moments of agent row i (for the pooled critic moments)
@@ -896,8 +886,8 @@ __global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatPara
             if (lane == i) { h[0] = v0; h[1] = v1; h[2] = p0; h[3] = p1; }
             if (other) { const int k = lane < i ? lane : lane - 1; h[4 + 2 * k] = rx; h[5 + 2 * k] = ry; }
         } else if (p.head || p.xc) {
-            float* h = p.head ? p.head + ((size_t)n * N + i) * HD : nullptr;
-            float* x = p.xc ? p.xc + (size_t)n * p.kc + i * HD : nullptr;
+            float* h = p.head ? p.head + (n * N + i) * HD : nullptr;
+            float* x = p.xc ? p.xc + n * p.kc + i * HD : nullptr;
             if (lane == i) {
                 if (h) { h[0] = v0; h[1] = v1; h[2] = p0; h[3] = p1; }
                 if (x) { x[0] = v0; x[1] = v1; x[2] = p0; x[3] = p1; }
@@ -928,20 +918,21 @@ __global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatPara
         for (int t = 0; t < PPL; ++t)
             if (t * 64 + lane < M) m2 += sq(fx[t]) + sq(fy[t]);
         m2 = wave_sum_f64_dpp(m2) + ((qe - 2.0 * mean * se) + (double)(3 * M) * mean * mean);
-        if (lane == 0 && p.stats) { p.stats[((size_t)n * N + i) * 2] = mean; p.stats[((size_t)n * N + i) * 2 + 1] = m2; }
+        if (lane == 0 && p.stats) { p.stats[(n * N + i) * 2] = mean; p.stats[(n * N + i) * 2 + 1] = m2; }
         if (lane == i) { my_mean = mean; my_m2 = m2; }
     }
     if (hrow) {     // N*HD = 2N(N+1) floats: a multiple of 4, rows of head / xc start 16-byte aligned
         wave_fence();
         const int n4 = (N * HD) >> 2;
         const float4* src = reinterpret_cast<const float4*>(hrow);
-        float4* dh = p.head ? reinterpret_cast<float4*>(p.head + (size_t)n * N * HD) : nullptr;
-        float4* dx = p.xc ? reinterpret_cast<float4*>(p.xc + (size_t)n * p.kc) : nullptr;
+        float4* dh = p.head ? reinterpret_cast<float4*>(p.head + n * N * HD) : nullptr;
+        float4* dx = p.xc ? reinterpret_cast<float4*>(p.xc + n * p.kc) : nullptr;
         for (int v = lane; v < n4; v += 64) {
             const float4 t = src[v];
             if (dh) dh[v] = t;
             if (dx) dx[v] = t;
         }
+        wave_fence();
     }
     if (p.cstats) {
         // moments of the centralised row = concatenation of the N agent rows (equal widths D): pooled mean, and
@@ -949,8 +940,86 @@ __global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatPara
         const double mean_e = wave_sum_f64_dpp(lane < N ? my_mean : 0.0) / (double)N;
         const double dm = my_mean - mean_e;
         const double m2_e = wave_sum_f64_dpp(lane < N ? my_m2 + (double)D * dm * dm : 0.0);
-        if (lane == 0) { p.cstats[(size_t)n * 2] = mean_e; p.cstats[(size_t)n * 2 + 1] = m2_e; }
+        if (lane == 0) { p.cstats[n * 2] = mean_e; p.cstats[n * 2 + 1] = m2_e; }
     }
+}
+
+template <int PPL>
+__global__ __launch_bounds__(kBlock) void dcc_obs_features_kernel(const FeatParams p) {
+    extern __shared__ __attribute__((aligned(16))) float feat_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x * kWavesPerBlock + wid;
+    if (n >= p.n) return;
+    const int N = p.N, M = p.M, HD = 4 + 2 * (N - 1);
+    // The head values of agent i come from different lanes (own vel / pos from lane i, the relative position of UAV a from
+    // lane a): written straight to HBM they are 4-byte stores at an 8-byte stride, 4 store instructions per agent that
+    // each touch a cache line partially.  Staged per wave in LDS (N*HD floats) they leave as two float4 runs per state.
+    float* hrow = p.stage ? feat_lds + (size_t)wid * N * HD : nullptr;
+    double2 mp = make_double2(0.0, 0.0), mv = mp;
+    if (lane < N) { mp = p.pos[(size_t)n * N + lane]; mv = p.vel[(size_t)n * N + lane]; }
+    double qx[PPL], qy[PPL];
+    float en[PPL];
+    unsigned dmask = 0;
+#pragma unroll
+    for (int t = 0; t < PPL; ++t) {
+        const int j = t * 64 + lane;
+        qx[t] = qy[t] = 0.0; en[t] = 0.f;
+        if (j < M) {
+            const double2 q = p.poi[j];
+            qx[t] = q.x; qy[t] = q.y;
+            en[t] = p.energy[(size_t)n * M + j];
+            if (p.done[(size_t)n * M + j]) dmask |= 1u << t;
+        }
+    }
+    produce_features<PPL>(p, (size_t)n, lane, hrow, mp, mv, qx, qy, en, dmask);
+}
+
+// ---- kernel 6: env step(s) + the policy-input features of the state each step leaves (dcc_env_step_features) -------------
+// The policy-driven rollout alternates a K = 1 env launch and the policy forward, and with structured first layers the
+// forward reads the FEATURES of the new state, not its rows.  Produced by a second launch they cost a launch, a round trip of
+// the state through HBM / L2 and a latency-bound kernel of their own (23 us per step at c3, 131 us at the c5 shard); here the
+// wave that stepped the env derives them from the registers it still holds.  float32 actions only (the rollout's dtype).
+template <int PPL, bool FORCE, int NC, int MC>
+__global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? (PPL >= 4 ? 2 : 3) : 4))) void dcc_env_feat_kernel(const KParams p, const FeatParams f) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int env = xcd_swizzle(blockIdx.x, gridDim.x) * kWavesPerBlock + wid;
+    constexpr bool SPEC = NC > 0;
+    const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
+    double2* s_poi = reinterpret_cast<double2*>(smem);
+    const int per_wave = N * 32 + kStageC * 4;
+    unsigned char* wbase = smem + ((M * 16 + 15) & ~15) + wid * per_wave;
+    double2* apos = reinterpret_cast<double2*>(wbase);
+    double2* avel = apos + N;
+    float* stg = reinterpret_cast<float*>(avel + N);
+    if (!PoiLane<PPL>::REG) {
+        for (int j = threadIdx.x; j < M; j += kBlock) s_poi[j] = p.poi[j];
+        __syncthreads();
+    }
+    if (env >= p.E) return;
+    EnvRegs<PPL> r;
+    PoiLane<PPL> poi;
+    ActFetch<act_rf<PPL, FORCE>()> af;
+    init_act(af);
+    prefetch_actions<PPL, 0, FORCE, NC>(p, env, lane, af);
+    poi.init(PoiLane<PPL>::REG ? p.poi : s_poi, lane, M);
+    load_env_state<PPL>(p, env, lane, N, M, r);
+    if (lane < N) { apos[lane] = make_double2(r.px, r.py); avel[lane] = make_double2(r.vx, r.vy); }
+    wave_fence();
+    for (int k = 0; k < p.K; ++k) {
+        env_physics_step<PPL, 0, FORCE, NC, MC>(p, env, k, lane, r, af, poi, apos, apos, avel);
+        const size_t ko = (size_t)k * p.E + env;
+        if (p.st_pos || p.st_vel || p.st_energy || p.st_done) write_step_state<PPL>(p, ko, lane, N, M, r);
+        double qx[PPL], qy[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) { const double2 pj = poi.get(q); qx[q] = pj.x; qy[q] = pj.y; }
+        double2 mp = make_double2(0.0, 0.0), mv = mp;
+        if (lane < N) { mp = make_double2(r.px, r.py); mv = make_double2(r.vx, r.vy); }
+        produce_features<PPL>(f, ko, lane, f.stage ? stg : nullptr, mp, mv, qx, qy, r.en, r.dmask);
+    }
+    store_env_state<PPL>(p, env, lane, N, M, r);
 }
 
 // ---- kernel 2: role-specialised -- a PHYSICS wave and an OBSERVATION wave per workgroup --------------------
@@ -1284,6 +1353,11 @@ struct dcc_env {
     uint8_t* d_done = nullptr;
     size_t lds_bytes = 0, lds_bytes_roles = 0, lds_bytes_split = 0;
     bool no_spec = false, no_roles = false, force_roles = false, no_split = false, force_split = false;
+    // create-time choice between the role-specialised and the fused kernel for obs-writing multi-step launches with one PoI
+    // per lane (which of the two streams faster depends on the box: DESIGN.md 4.1); tune_us: measured us per step of each
+    bool prefer_fused = false;
+    int tuned = 0;              // 0: not measured (shape not eligible, disabled, or the measurement failed), 1: measured
+    float tune_us[2] = {0.f, 0.f};   // [0] role-specialised, [1] fused
 };
 
 namespace {
@@ -1360,6 +1434,25 @@ kernel_fn pick_split_kernel(int ppl, int act, bool force, int n, int m, bool all
     return act == 0 ? pick_split<0, false>(ppl, n, m, allow_spec) : pick_split<2, false>(ppl, n, m, allow_spec);
 }
 
+typedef void (*feat_kernel_fn)(const KParams, const FeatParams);
+
+template <bool FORCE>
+feat_kernel_fn pick_feat_kernel(int ppl, int n, int m, bool allow_spec) {
+    if (allow_spec) {
+        if (n == 8 && m == 64) return dcc_env_feat_kernel<1, FORCE, 8, 64>;
+        if (n == 4 && m == 16) return dcc_env_feat_kernel<1, FORCE, 4, 16>;
+        if (n == 4 && m == 20) return dcc_env_feat_kernel<1, FORCE, 4, 20>;
+        if (n == 16 && m == 256) return dcc_env_feat_kernel<4, FORCE, 16, 256>;
+    }
+    switch (ppl) {
+        case 1: return dcc_env_feat_kernel<1, FORCE, 0, 0>;
+        case 2: return dcc_env_feat_kernel<2, FORCE, 0, 0>;
+        case 4: return dcc_env_feat_kernel<4, FORCE, 0, 0>;
+        case 8: return dcc_env_feat_kernel<8, FORCE, 0, 0>;
+        default: return dcc_env_feat_kernel<16, FORCE, 0, 0>;
+    }
+}
+
 // act: 0 = f32 actions, 1 = f64 actions, 2 = in-kernel generator
 int launch(dcc_env* env, KParams& p, int act, void* stream) {
     // specialised kernels assume float4-aligned obs rows; DCC_NO_SPEC=1 forces the generic kernels (tests)
@@ -1369,7 +1462,8 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
     // (DCC_NO_ROLES=1 forces the fused kernel: tests, A/B)
     // and only for fused multi-step launches: with K = 1 there is nothing to pipeline and the hand-off only adds
     // latency (13.4 vs 14.3 us per single-step launch); DCC_FORCE_ROLES=1 overrides (tests)
-    if (p.obs != nullptr && env->PPL == 1 && !env->no_roles && (p.K >= 2 || env->force_roles)) {
+    if (p.obs != nullptr && env->PPL == 1 && !env->no_roles && (p.K >= 2 || env->force_roles) &&
+        !(env->prefer_fused && !env->force_roles)) {
         kernel_fn fn = pick_roles_kernel(act, p.use_force != 0, p.N, p.M, allow_spec);
         const int grid = (p.E + 1) / 2;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kRolesBlock), env->lds_bytes_roles, s, p);
@@ -1430,6 +1524,57 @@ int fill_out(KParams& p, const dcc_env_out* out) {
     p.st_done = out ? out->state_done : nullptr;
     p.vec_ok = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 15u) == 0);
     return DCC_OK;
+}
+
+// Create-time A/B of the two kernel shapes an obs-writing K-step launch can take when there is one PoI per lane: the same
+// short rollout (in-kernel action stream, observation rows into a scratch buffer) through each, timed with HIP events on
+// a private stream; the faster one is used from then on (both are bit-identical: tests/test_env_hip_parity.py runs every
+// golden case through both).  The env state is reset afterwards, i.e. left exactly as dcc_env_create leaves it.
+void autotune_kernel_shape(dcc_env* e) {
+    const char* at = std::getenv("DCC_AUTOTUNE");
+    if ((at && at[0] == '0') || e->PPL != 1 || e->no_roles || e->force_roles) return;
+    const size_t step_bytes = (size_t)e->cfg.n_envs * (size_t)e->L * sizeof(float);
+    if (step_bytes < ((size_t)8 << 20)) return;          // small batches are latency-bound: keep the default
+    const int K = 16;
+    float* scratch = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    if (hipMalloc(&scratch, step_bytes * K) != hipSuccess) { (void)hipGetLastError(); return; }
+    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&ev[0]) == hipSuccess &&
+              hipEventCreate(&ev[1]) == hipSuccess;
+    float best[2] = {1e30f, 1e30f};
+    for (int rep = 0; ok && rep < 3; ++rep) {              // rep 0 warms both up
+        for (int v = 0; ok && v < 2; ++v) {
+            KParams p = e->base;
+            p.mode = 0; p.K = K; p.actions = nullptr; p.seed = 0x5eedULL + rep; p.step0 = 0; p.env0 = 0; p.env_total = e->cfg.n_envs;
+            dcc_env_out o;
+            std::memset(&o, 0, sizeof(o));
+            o.obs = scratch;
+            fill_out(p, &o);
+            e->prefer_fused = (v == 1);
+            ok = hipEventRecord(ev[0], st) == hipSuccess && launch(e, p, 2, st) == DCC_OK && hipEventRecord(ev[1], st) == hipSuccess &&
+                 hipEventSynchronize(ev[1]) == hipSuccess;
+            float ms = 0.f;
+            if (ok) ok = hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
+            if (ok && rep > 0 && ms < best[v]) best[v] = ms;
+        }
+    }
+    e->prefer_fused = false;
+    if (ok) {
+        e->tune_us[0] = best[0] * 1e3f / K; e->tune_us[1] = best[1] * 1e3f / K;
+        e->prefer_fused = best[1] < 0.985f * best[0];      // the role-specialised shape keeps ties (it wins on most boxes)
+        e->tuned = 1;
+    } else {
+        (void)hipGetLastError();
+    }
+    // back to the reset state
+    const size_t E = e->cfg.n_envs, N = e->cfg.n_agents, M = e->cfg.n_pois;
+    (void)hipMemset(e->d_pos, 0, sizeof(double2) * E * N); (void)hipMemset(e->d_vel, 0, sizeof(double2) * E * N);
+    (void)hipMemset(e->d_energy, 0, sizeof(float) * E * M); (void)hipMemset(e->d_done, 0, E * M);
+    if (ev[0]) (void)hipEventDestroy(ev[0]);
+    if (ev[1]) (void)hipEventDestroy(ev[1]);
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(scratch);
 }
 
 struct DeviceGuard {
@@ -1553,8 +1698,17 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
         (err = hipMemset(e->d_done, 0, (size_t)E * M)) != hipSuccess)
         return cleanup(DCC_EHIP, std::string("dcc_env_create: init copy: ") + hipGetErrorString(err));
     p.poi = e->d_poi; p.pos = e->d_pos; p.vel = e->d_vel; p.energy = e->d_energy; p.done_poi = e->d_done;
+    autotune_kernel_shape(e);
     *out = e;
     return DCC_OK;
+}
+
+int dcc_env_kernel_choice(const dcc_env* e, float* us_roles, float* us_fused) {
+    if (!e) return fail(DCC_EINVAL, "dcc_env_kernel_choice: null env");
+    if (us_roles) *us_roles = e->tune_us[0];
+    if (us_fused) *us_fused = e->tune_us[1];
+    if (!e->tuned) return 0;
+    return e->prefer_fused ? 2 : 1;
 }
 
 int dcc_env_destroy(dcc_env* e) {
@@ -1607,6 +1761,35 @@ int dcc_env_step(dcc_env* e, const void* actions, int act_dtype, const dcc_env_o
     p.mode = 0; p.K = 1; p.actions = actions;
     fill_out(p, out);
     return launch(e, p, act_dtype == DCC_ACT_F64 ? 1 : 0, stream);
+}
+
+int dcc_env_step_features(dcc_env* e, const void* actions, int act_dtype, const dcc_env_out* out, const dcc_obs_feat* feat,
+                          void* stream) {
+    if (!e) return fail(DCC_EINVAL, "dcc_env_step_features: null env");
+    if (!actions || !feat) return fail(DCC_EINVAL, "dcc_env_step_features: actions / feat is NULL");
+    if (act_dtype != DCC_ACT_F32) return fail(DCC_EUNSUPPORTED, "dcc_env_step_features: float32 actions only (use dcc_env_step + dcc_obs_features)");
+    if (out && out->obs) return fail(DCC_EINVAL, "dcc_env_step_features: observation rows are not written by this entry point (out->obs must be NULL)");
+    if (reinterpret_cast<uintptr_t>(actions) & 7u) return fail(DCC_EINVAL, "dcc_env_step_features: actions pointer misaligned");
+    DeviceGuard guard(e->device);
+    KParams p = e->base;
+    p.mode = 0; p.K = 1; p.actions = actions;
+    fill_out(p, out);
+    FeatParams f;
+    std::memset(&f, 0, sizeof(f));
+    f.poi = e->d_poi;
+    f.head = feat->head; f.poi_feat = feat->poi_feat; f.stats = feat->stats; f.cstats = feat->cstats; f.xa = feat->xa; f.xc = feat->xc;
+    f.n = p.E; f.N = p.N; f.M = p.M; f.m_energy = (float)e->cfg.m_energy;
+    f.ka = (2 * p.M + 1 + 7) / 8 * 8;
+    f.kc = (p.N * (4 + 2 * (p.N - 1)) + 2 * p.M + 1 + 7) / 8 * 8;
+    const auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    f.stage = (f.head || f.xc) && p.N * (4 + 2 * (p.N - 1)) <= kStageC && a16(f.head) && a16(f.xc);
+    feat_kernel_fn fn = p.use_force ? pick_feat_kernel<true>(e->PPL, p.N, p.M, !e->no_spec) : pick_feat_kernel<false>(e->PPL, p.N, p.M, !e->no_spec);
+    const int grid = (p.E + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (e->lds_bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), e->lds_bytes, reinterpret_cast<hipStream_t>(stream), p, f);
+    HIP_TRY(hipGetLastError());
+    return DCC_OK;
 }
 
 int dcc_env_rollout(dcc_env* e, int32_t K, const float* actions, uint64_t seed, uint32_t step0, int32_t env0,

@@ -571,12 +571,18 @@ __global__ __launch_bounds__(kBlock) void rollout_sample_k(const float* __restri
 
 __global__ __launch_bounds__(kBlock) void rollout_record_k(const float* __restrict__ reward, const unsigned char* __restrict__ done,
                                                            float* __restrict__ rewards, float* __restrict__ masks_next,
-                                                           long long R, int N) {
+                                                           long long R, int N, const float* __restrict__ coverage,
+                                                           double* __restrict__ rew_acc, float* __restrict__ cov_max) {
     const long long r = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (r >= R) return;
     const long long e = r / N;
-    rewards[r] = reward[e];
+    const float rw = reward[e];
+    rewards[r] = rw;
     masks_next[r] = done[e] ? 0.f : 1.f;                         // masks = 1 - done (learner.py:262-264)
+    if (r == e * N) {   // the env's first agent row also keeps the env's logged statistics (learner.py:187-193): element-wise, no reduction
+        if (rew_acc) rew_acc[e] += (double)rw;
+        if (cov_max && coverage) cov_max[e] = fmaxf(cov_max[e], coverage[e]);
+    }
 }
 
 // ---- actor first block from compact features -------------------------------------------------------------------
@@ -1341,7 +1347,18 @@ DCC_API int dcc_rollout_record(const float* reward, const uint8_t* done, float* 
                                int32_t N, void* stream) {
     if (!reward || !done || !rewards || !masks_next || R < 1 || N < 1) return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer, size, or an array that is not 16-byte aligned)");
     hipLaunchKernelGGL(rollout_record_k, dim3((unsigned)((R + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       reinterpret_cast<hipStream_t>(stream), reward, done, rewards, masks_next, (long long)R, (int)N);
+                       reinterpret_cast<hipStream_t>(stream), reward, done, rewards, masks_next, (long long)R, (int)N,
+                       (const float*)nullptr, (double*)nullptr, (float*)nullptr);
+    return launch_status(__func__);
+}
+
+DCC_API int dcc_rollout_record_stats(const float* reward, const uint8_t* done, const float* coverage, float* rewards,
+                                     float* masks_next, double* rew_acc, float* cov_max, int64_t R, int32_t N, void* stream) {
+    if (!reward || !done || !rewards || !masks_next || R < 1 || N < 1 || (cov_max && !coverage))
+        return dcc_fail(kEINVAL, std::string(__func__) + ": invalid argument (null pointer or size)");
+    hipLaunchKernelGGL(rollout_record_k, dim3((unsigned)((R + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), reward, done, rewards, masks_next, (long long)R, (int)N, coverage,
+                       rew_acc, cov_max);
     return launch_status(__func__);
 }
 

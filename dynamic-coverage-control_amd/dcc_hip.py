@@ -40,12 +40,16 @@ class EnvOut(ctypes.Structure):
                 ("state_pos", _vp), ("state_vel", _vp), ("state_energy", _vp), ("state_done", _vp)]
 
 
+class ObsFeat(ctypes.Structure):       # include/dcc_env.h: dcc_obs_feat
+    _fields_ = [("head", _vp), ("poi_feat", _vp), ("stats", _vp), ("cstats", _vp), ("xa", _vp), ("xc", _vp)]
+
+
 EXPORTS = ["dcc_obs_expand", "dcc_gae_compute", "dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
-           "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout", "dcc_env_get_state",
-           "dcc_env_set_state", "dcc_env_bytes_per_step", "dcc_obs_features", "dcc_obs_features_x",
+           "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_step_features", "dcc_env_rollout", "dcc_env_get_state",
+           "dcc_env_set_state", "dcc_env_bytes_per_step", "dcc_env_kernel_choice", "dcc_obs_features", "dcc_obs_features_x",
            "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_relu_ln_head_fwd", "dcc_relu_ln_head_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd", "dcc_actor_l1_pre_fwd", "dcc_actor_l1_pre_bwd",
            "dcc_ppo_policy_loss",
-           "dcc_rollout_sample", "dcc_rollout_record", "dcc_ppo_value_loss",
+           "dcc_rollout_sample", "dcc_rollout_record", "dcc_rollout_record_stats", "dcc_ppo_value_loss",
            "dcc_grad_norm_workspace_floats", "dcc_grad_norm_clip", "dcc_adam_step"]
 
 _lib = None
@@ -76,6 +80,8 @@ def load_library(path=None):
     L.dcc_env_set_state.argtypes = [_vp] * 6
     L.dcc_env_bytes_per_step.argtypes = [ctypes.c_int32] * 4
     L.dcc_env_bytes_per_step.restype = ctypes.c_int64
+    L.dcc_env_kernel_choice.argtypes = [_vp, _vp, _vp]
+    L.dcc_env_step_features.argtypes = [_vp, _vp, ctypes.c_int, ctypes.POINTER(EnvOut), ctypes.POINTER(ObsFeat), _vp]
     L.dcc_gae_compute.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, ctypes.c_int32,
                                   ctypes.c_int64, _vp]
     L.dcc_obs_expand.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]
@@ -90,6 +96,7 @@ def load_library(path=None):
     L.dcc_ppo_value_loss.argtypes = [_vp] * 5 + [f32, f32, i32, _vp, _vp, _vp, i64, i32, _vp]
     L.dcc_rollout_sample.argtypes = [_vp] * 7 + [i64, i32, i32, i32, _vp]
     L.dcc_rollout_record.argtypes = [_vp] * 4 + [i64, i32, _vp]
+    L.dcc_rollout_record_stats.argtypes = [_vp] * 7 + [i64, i32, _vp]
     L.dcc_mlp_workspace_floats.argtypes = [i32, i32]
     L.dcc_mlp_workspace_floats.restype = i64
     L.dcc_actor_l1_fwd.argtypes = [_vp] * 8 + [f32, f32, i32, _vp, i64, i32, i32, i32, _vp]
@@ -164,6 +171,15 @@ class HipCoverageEnv:
             pass
 
     # ---- allocation helpers ---------------------------------------------------------------------
+    def kernel_choice(self):
+        """{"choice": "roles" | "fused" | "default", "us_per_step_roles", "us_per_step_fused"}: what dcc_env_create measured on
+        this device for obs-writing multi-step launches (include/dcc_env.h: dcc_env_kernel_choice)."""
+        a, b = ctypes.c_float(0.0), ctypes.c_float(0.0)
+        rc = self.lib.dcc_env_kernel_choice(self._h, ctypes.byref(a), ctypes.byref(b))
+        if rc < 0:
+            raise DccError("dcc_env_kernel_choice failed (%d): %s" % (rc, load_library().dcc_last_error().decode()))
+        return {"choice": {0: "default", 1: "roles", 2: "fused"}[rc], "us_per_step_roles": a.value, "us_per_step_fused": b.value}
+
     def alloc_out(self, K=None, obs=True, assign=True, reward64=False):
         lead = () if K is None else (K,)
         mk = lambda shape, dt: torch.empty(lead + shape, dtype=dt, device=self.device)
@@ -213,11 +229,7 @@ class HipCoverageEnv:
         for t, shape, dt in want:
             if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
                 raise ValueError("obs_features: need contiguous %s %s on %s" % (shape, dt, self.device))
-        HD = 4 + 2 * (self.N - 1)
-        ka, kc = (2 * self.M + 1 + 7) // 8 * 8, (self.N * HD + 2 * self.M + 1 + 7) // 8 * 8
-        shapes = dict(head=((n, self.N, HD), torch.float32), poi_feat=((n, 2 * self.M), torch.float32),
-                      stats=((n, self.N, 2), torch.float64), cstats=((n, 2), torch.float64),
-                      xa=((n, ka), torch.float32), xc=((n, kc), torch.float32))
+        shapes = self.feature_shapes(n)
         if out is None:
             out = {k: torch.empty(sh, dtype=dt, device=self.device) for k, (sh, dt) in shapes.items()}
         for k, (sh, dt) in shapes.items():
@@ -287,6 +299,47 @@ class HipCoverageEnv:
         o = self._out_struct(out)
         with torch.cuda.device(self.device):
             _check(self.lib.dcc_env_step(self._h, _ptr(actions), dt, ctypes.byref(o), _stream()), "dcc_env_step")
+        return out
+
+    def feature_shapes(self, n):
+        """name -> (shape, dtype) of the feature tensors of n states (dcc_obs_features_x / dcc_env_step_features)."""
+        HD = 4 + 2 * (self.N - 1)
+        ka, kc = (2 * self.M + 1 + 7) // 8 * 8, (self.N * HD + 2 * self.M + 1 + 7) // 8 * 8
+        return dict(head=((n, self.N, HD), torch.float32), poi_feat=((n, 2 * self.M), torch.float32),
+                    stats=((n, self.N, 2), torch.float64), cstats=((n, 2), torch.float64),
+                    xa=((n, ka), torch.float32), xc=((n, kc), torch.float32))
+
+    def alloc_features(self, n=None, keys=("head", "stats", "cstats", "xa", "xc")):
+        return {k: torch.empty(sh, dtype=dt, device=self.device) for k, (sh, dt) in self.feature_shapes(n or self.E).items() if k in keys}
+
+    def step_features(self, actions, out, feat):
+        """One env step + the policy-input features of the state it leaves, in ONE launch (dcc_env_step_features).  `out`: as
+        for step(), without "obs"; `feat`: dict of destination tensors (feature_shapes(E)); missing keys are skipped."""
+        if (actions.device != self.device or not actions.is_contiguous() or tuple(actions.shape) != (self.E, self.N, 2)
+                or actions.dtype != torch.float32):
+            raise ValueError("actions must be a contiguous float32 [E,N,2] tensor on %s" % self.device)
+        if out.get("obs") is not None:
+            raise ValueError("step_features writes no observation rows")
+        o = self._out_struct(out)
+        key = tuple((k, t.data_ptr(), tuple(t.shape), t.dtype) for k, t in feat.items())
+        cached = getattr(self, "_feat_structs", None)
+        if cached is None:
+            cached = self._feat_structs = {}
+        fs = cached.get(key)
+        if fs is None:
+            shapes = self.feature_shapes(self.E)
+            fs = ObsFeat()
+            for k, t in feat.items():
+                sh, dt = shapes[k]
+                if tuple(t.shape) != sh or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                    raise ValueError("step_features: output %r must be contiguous %s %s on %s" % (k, sh, dt, self.device))
+                setattr(fs, k, t.data_ptr())
+            if len(cached) > 8:
+                cached.clear()
+            cached[key] = fs
+        with torch.cuda.device(self.device):
+            _check(self.lib.dcc_env_step_features(self._h, _ptr(actions), ACT_F32, ctypes.byref(o), ctypes.byref(fs), _stream()),
+                   "dcc_env_step_features")
         return out
 
     def rollout(self, K, actions=None, seed=0, step0=0, env0=0, env_total=None, out=None):
@@ -458,13 +511,23 @@ def rollout_sample(mean, logstd, eps, value, actions_out, logp_out, value_preds_
                                                  _stream()), "dcc_rollout_sample")
 
 
-def rollout_record(reward, done, rewards_out, masks_out, n_agents):
+def rollout_record(reward, done, rewards_out, masks_out, n_agents, coverage=None, rew_acc=None, cov_max=None):
+    """rewards / masks of one env step into their buffer slots; with rew_acc (f64 [E]) / cov_max (f32 [E]) also the per-env
+    logged statistics in the same launch (rew_acc += reward, cov_max = max(cov_max, coverage))."""
     R = rewards_out.numel()
     if reward.dtype != torch.float32 or done.dtype != torch.uint8 or not rewards_out.is_contiguous() or not masks_out.is_contiguous():
         raise ValueError("rollout_record: reward f32 [E], done u8 [E], contiguous float32 outputs")
     with torch.cuda.device(reward.device):
-        _check(load_library().dcc_rollout_record(_ptr(reward), _ptr(done), _ptr(rewards_out), _ptr(masks_out), R, n_agents,
-                                                 _stream()), "dcc_rollout_record")
+        if rew_acc is None and cov_max is None:
+            _check(load_library().dcc_rollout_record(_ptr(reward), _ptr(done), _ptr(rewards_out), _ptr(masks_out), R, n_agents,
+                                                     _stream()), "dcc_rollout_record")
+            return
+        if (rew_acc is not None and (rew_acc.dtype != torch.float64 or not rew_acc.is_contiguous())) or \
+                (cov_max is not None and (cov_max.dtype != torch.float32 or not cov_max.is_contiguous() or coverage is None
+                                          or coverage.dtype != torch.float32)):
+            raise ValueError("rollout_record: rew_acc f64 [E], cov_max / coverage f32 [E]")
+        _check(load_library().dcc_rollout_record_stats(_ptr(reward), _ptr(done), _ptr(coverage), _ptr(rewards_out), _ptr(masks_out),
+                                                       _ptr(rew_acc), _ptr(cov_max), R, n_agents, _stream()), "dcc_rollout_record_stats")
 
 
 def actor_l1_fwd(head, G, stats, Wh, s, c, gamma, beta, eps_in, eps_ln, D):

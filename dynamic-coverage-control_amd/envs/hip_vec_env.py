@@ -85,12 +85,14 @@ class HipCoverageVecEnv:
     def reset_device(self, obs_out=None):
         return self.env.reset(obs_out)
 
-    def step_device(self, actions, obs_out=None, out=None, extra_out=None, want_obs=True):
+    def step_device(self, actions, obs_out=None, out=None, extra_out=None, want_obs=True, features_out=None):
         """actions: [E,N,2] float32/float64 tensor on the device.  Returns the dict of output tensors
         (obs, reward [E], done [E] u8, connect, connect_s, coverage [E], assign [E,M]).  `obs_out` lets
         the caller name the destination of the observations (e.g. a rollout-buffer slot).  The small
         per-step tensors are REUSED by the next call (no allocation per step): consume or copy them first.
-        `extra_out` adds outputs to that dict (e.g. the compact state_* slots of a rollout buffer)."""
+        `extra_out` adds outputs to that dict (e.g. the compact state_* slots of a rollout buffer).
+        `features_out` (with want_obs=False, float32 actions): dict of feature tensors (HipCoverageEnv.feature_shapes) that the
+        SAME launch fills with the policy-input features of the post-step state (dcc_env_step_features)."""
         if out is None:
             if self._out is None:
                 self._out = self.env.alloc_out(obs=False)
@@ -100,6 +102,8 @@ class HipCoverageVecEnv:
                     (self.n_envs, self.n_agents, self.obs_dim), dtype=torch.float32, device=self.device)
             if extra_out:
                 out.update(extra_out)
+        if features_out is not None and not want_obs and actions.dtype == torch.float32:
+            return self.env.step_features(actions, out, features_out)
         return self.env.step(actions, out)
 
     # ---- numpy surface (reference contract) ----------------------------------------------------------

@@ -125,6 +125,7 @@ class Learner:
         # graph (reward sum, running max of the coverage rate) and reduced over the envs after the replay, outside capture
         # (multi-block torch reductions inside a replayed graph are not reliable on this stack: tools/graph_reduce_probe.py).
         self._graphs = {}
+        self._step_features = bool(getattr(self.cfg, "step_features", True)) and ptu.device.type == "cuda"
         self.use_hip_graph = bool(self.cfg.use_hip_graph) and ptu.device.type == "cuda" and not self.recurrent
 
     def _make_buffer(self, envs):
@@ -178,15 +179,19 @@ class Learner:
                 values, actions, action_log_probs = self.collect(cur_step, r_buffer)
             # rows are written unless the policy reads features AND the buffer does not keep rows
             want_rows = not (r_buffer.structured and r_buffer.compact)
+            # structured input without rows: the env launch also derives the features of the state it leaves (one launch
+            # instead of two, the state never re-read: include/dcc_env.h dcc_env_step_features)
+            feats = (r_buffer.feature_slot(cur_step + 1, r_envs.env.alloc_features)
+                     if (not want_rows and self._step_features and actions.dtype == torch.float32) else None)
             out = r_envs.step_device(actions, obs_out=r_buffer.obs_slot(cur_step + 1) if want_rows else None,
-                                     extra_out=r_buffer.state_slot(cur_step + 1), want_obs=want_rows)
+                                     extra_out=r_buffer.state_slot(cur_step + 1), want_obs=want_rows, features_out=feats)
             if fused_glue:      # rewards / masks of the env step into their buffer slots (dcc_rollout_record)
                 import dcc_hip
                 dcc_hip.rollout_record(out["reward"], out["done"], r_buffer.rewards[cur_step], r_buffer.masks[cur_step + 1],
-                                       self.n_agents)
+                                       self.n_agents, coverage=out["coverage"], rew_acc=rew_acc, cov_max=cov_max)   # + the logged statistics
                 r_buffer.step = (cur_step + 1) % r_buffer.episode_length
-            else:
-                self.insert((out, values, actions, action_log_probs, rnn_a, rnn_c), r_buffer)
+                continue
+            self.insert((out, values, actions, action_log_probs, rnn_a, rnn_c), r_buffer)
             rew_acc += out["reward"]
             cov_max = torch.maximum(cov_max, out["coverage"])
         self.compute(r_buffer)
@@ -413,7 +418,7 @@ class Learner:
 
     # ---- headless evaluation ---------------------------------------------------------
     @torch.no_grad()
-    def evaluate(self, envs=None, steps=None, deterministic=False, dump_path=None):
+    def evaluate(self, envs=None, steps=None, deterministic=False, dump_path=None, noise_scale=1.0):
         """Roll the current policy without learning and report the metrics of the reference's README curves
         (coverage rate, steps needed to cover every PoI).  `dump_path` gets the trajectory as an .npz -- the headless
         stand-in for the pyglet viewer: per step the ACTIONS fed to the env and what they led to (post-step, post-auto-reset
@@ -423,7 +428,10 @@ class Learner:
         Actions are SAMPLED by default, like the reference's test / render rollouts (learner.py:143-149 run the same
         `collect` as training); deterministic=True plays the distribution's mean instead.  The two differ a lot for this
         task: the policy trained for 1500 iterations on the shipped scenario covers every PoI in 44 steps when sampled
-        and stalls at half coverage on its mean (profiles/r02/training_run_1500_iters_and_shard_mappo.txt)."""
+        and stalls at half coverage on its mean (profiles/r02/training_run_1500_iters_and_shard_mappo.txt): all UAVs start at
+        the origin with identical observations, so identical means never separate them.  noise_scale tempers the sampling,
+        a = mean + noise_scale * std * eps (1.0 = the policy's own distribution, 0.0 = its mean): how much of the
+        steps-to-cover figure is exploration noise rather than policy quality (profiles/r03/training_run_*.txt)."""
         envs = envs if envs is not None else (self.test_envs if self.test_envs is not None else self.train_envs)
         T = steps or self.max_ep_len
         E, N = envs.n_envs, self.n_agents
@@ -437,7 +445,12 @@ class Learner:
             rnn = torch.zeros(E * N, self.cfg.recurrent_N, self.cfg.algo_hidden_size, device=ptu.device)
             masks = torch.ones(E * N, 1, device=ptu.device)
         for t in range(T):
-            actions, _, rnn = self.policy.actor(obs.view(E * N, -1), rnn, masks, deterministic=deterministic)
+            if deterministic or noise_scale == 1.0:
+                actions, _, rnn = self.policy.actor(obs.view(E * N, -1), rnn, masks, deterministic=deterministic)
+            else:
+                mean, rnn = self.policy.actor._mean(obs.view(E * N, -1), rnn_states=rnn, masks=masks, want_states=True)
+                std = self.policy.actor.act.action_out.logstd._bias.view(1, -1).exp()
+                actions = mean + float(noise_scale) * std * torch.randn_like(mean)
             actions = actions.view(E, N, -1).contiguous()
             out = envs.step_device(actions)
             obs = out["obs"]

@@ -164,9 +164,33 @@ DCC_API int dcc_obs_features_x(dcc_env* env, int64_t n, const double* pos, const
                                const uint8_t* done, float* head, float* poi_feat, double* stats, double* cstats,
                                float* xa, float* xc, void* stream);
 
+/* One env step AND the compact policy-input features of the state it leaves, in one launch: what dcc_env_step followed by
+ * dcc_obs_features_x on the emitted state computes (bit-identical), without the second launch and without re-reading the
+ * state -- the wave that stepped an env derives the features from its registers.  This is the step of a policy-driven
+ * rollout with structured first layers (reference learner.py:178-214: collect -> envs.step -> insert).
+ * out: like dcc_env_step, but out->obs must be NULL (rows are exactly what this path avoids).  feat: destinations as in
+ * dcc_obs_features_x with n = n_envs; any may be NULL.  float32 actions only (DCC_EUNSUPPORTED otherwise). */
+typedef struct dcc_obs_feat {
+    float* head;       /* [E, N, 4+2(N-1)] */
+    float* poi_feat;   /* [E, 2M]          */
+    double* stats;     /* [E, N, 2]        */
+    double* cstats;    /* [E, 2]           */
+    float* xa;         /* [E, pad8(2M+1)]  */
+    float* xc;         /* [E, pad8(N(4+2(N-1)) + 2M + 1)] */
+} dcc_obs_feat;
+DCC_API int dcc_env_step_features(dcc_env* env, const void* actions, int act_dtype, const dcc_env_out* out,
+                                  const dcc_obs_feat* feat, void* stream);
+
 /* Algorithmic HBM bytes of one env-step (SURVEY.md section 8d, fp32 I/O contract):
  * 40N + 11M + 11 + 4*N*D; with_actions=0 drops 8N; with_obs=0 drops 4*N*D. */
 DCC_API int64_t dcc_env_bytes_per_step(int32_t n_agents, int32_t n_pois, int32_t with_actions, int32_t with_obs);
+
+/* Which kernel shape obs-writing multi-step launches of this env use, as measured by dcc_env_create on THIS device (a short
+ * rollout through each shape; batches of >= 8 MB of observation rows per step with <= 64 PoIs; DCC_AUTOTUNE=0 disables):
+ * returns 0 = not measured (the built-in default applies), 1 = role-specialised (a physics wave + an observation wave per
+ * two envs), 2 = fused (one wave per env); the measured microseconds per batched step go to us_roles / us_fused (may be
+ * NULL).  Both shapes produce bit-identical outputs. */
+DCC_API int dcc_env_kernel_choice(const dcc_env* env, float* us_roles, float* us_fused);
 
 #ifdef __cplusplus
 }

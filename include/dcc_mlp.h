@@ -105,6 +105,11 @@ DCC_API int dcc_rollout_sample(const float* mean, const float* logstd, const flo
                                float* logp, float* value_preds, int64_t R, int32_t N, int32_t A, int32_t K, void* stream);
 DCC_API int dcc_rollout_record(const float* reward, const uint8_t* done, float* rewards, float* masks_next, int64_t R,
                                int32_t N, void* stream);
+/* The same, and the per-env statistics the learner logs (reference learner.py:187-193: episode reward sum, coverage rate)
+ * kept in the same launch, element-wise per env: rew_acc[e] += reward[e] (f64), cov_max[e] = max(cov_max[e], coverage[e]).
+ * rew_acc / cov_max / coverage may be NULL (cov_max needs coverage). */
+DCC_API int dcc_rollout_record_stats(const float* reward, const uint8_t* done, const float* coverage, float* rewards,
+                                     float* masks_next, double* rew_acc, float* cov_max, int64_t R, int32_t N, void* stream);
 
 /*
  * Actor first block from compact features of n env states with N agents each (rows r = e*N + i):

@@ -20,6 +20,18 @@ def test_two_rank_gpu_training_keeps_replicas_identical():
     assert "DIST_GPU_OK" in r.stdout
 
 
+def test_train_py_as_a_two_rank_job(tmp_path):
+    """The launcher under torch.distributed.run, one process per rank (the ranks share the one GPU over the gloo test hook):
+    2 iterations, the checkpoint written collectively; test_two_gpus_over_rccl runs the same over RCCL where 2 GPUs exist."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", "train.py", "0", "n_iters=2", "n_rollout_threads=64", "n_eval_rollout_threads=0", "max_ep_len=10",
+           "ppo_epoch=2", "algo_hidden_size=32", "save_interval=2", "main_save_path=%s/" % tmp_path]
+    r = subprocess.run(cmd, cwd=os.path.join(ROOT, "dynamic-coverage-control_amd"), capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, DCC_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "iter: 2" in r.stdout and "model saved" in r.stdout and "2 GPUs" in r.stdout
+
+
 def test_single_rank_group_over_rccl():
     """What a 1-GPU box can run of the RCCL path: a ONE-rank process group over backend nccl (DCC_DIST_SINGLE=1) through every
     collective call site of the learner and of bench.py -- a host tensor handed to a collective or an operation RCCL lacks
@@ -57,3 +69,21 @@ def test_two_gpus_over_rccl():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2048 and "error" not in d["c3"], d["c3"]
     assert d["c3"]["grad_allreduce"] == "rccl x2" and all(v == v for v in d["c3"]["train_info"].values())
+    # the line proves the job it ran as: two distinct devices seen over RCCL, an all-reduce of ones == 2, the strong c2 figure
+    rc = d["rccl"]
+    assert rc["backend"] == "rccl" and rc["world_size"] == 2 and rc["allreduce_ok"] and rc["distinct_devices"] == 2, rc
+    assert "error" not in d["c2_strong"] and d["c2_strong"]["envs_per_gpu"] == 2048
+    # the replica-identity worker (parameters / ValueNorm digests equal on both ranks after 3 iterations, per-rank resume) over RCCL
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    r = subprocess.run(launcher + ["--master-port", "29551", os.path.join(ROOT, "tests", "_dist_gpu_worker.py")], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    # and the launcher itself: train.py for 2 iterations as a 2-rank job (one process per GPU), checkpoint written collectively
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run(launcher + ["--master-port", "29552", "train.py", "0", "n_iters=2", "n_rollout_threads=64",
+                                       "n_eval_rollout_threads=0", "max_ep_len=10", "ppo_epoch=2", "algo_hidden_size=32",
+                                       "save_interval=2", "main_save_path=%s/" % tmp],
+                           cwd=os.path.join(ROOT, "dynamic-coverage-control_amd"), capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "iter: 2" in r.stdout and "model saved" in r.stdout and "2 GPUs" in r.stdout

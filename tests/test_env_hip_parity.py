@@ -442,3 +442,81 @@ def test_obs_features_match_the_rows(N, M):
     assert torch.equal(only["stats"], f["stats"])
     with pytest.raises(ValueError):
         env.obs_features(st[0].float(), *st[1:])
+
+
+def test_kernel_shape_is_measured_at_create_and_both_shapes_agree(oracle_mod, monkeypatch):
+    """dcc_env_create times the role-specialised and the fused kernel shape on this device for batches that are large
+    enough (which one streams faster depends on the box) and keeps the faster; DCC_AUTOTUNE=0 keeps the
+    built-in default.  Whatever is chosen, the env starts from the reset state and steps like the oracle."""
+    import dcc_hip
+    for k in ("DCC_NO_ROLES", "DCC_FORCE_ROLES", "DCC_AUTOTUNE"):
+        monkeypatch.delenv(k, raising=False)
+    E, N, M = 4096, 8, 64
+    poi = np.load(os.path.join(os.path.dirname(__file__), "golden", "pos_pois.npy"))[:M]
+    big = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, 0.4, 0.95, 0.0)
+    kc = big.kernel_choice()
+    assert kc["choice"] in ("roles", "fused") and kc["us_per_step_roles"] > 0 and kc["us_per_step_fused"] > 0
+    assert (kc["choice"] == "fused") == (kc["us_per_step_fused"] < 0.985 * kc["us_per_step_roles"])
+    st = big.get_state()        # the measurement leaves the state dcc_env_create promises: every env at reset
+    assert float(st["pos"].abs().sum()) == 0.0 and float(st["energy"].abs().sum()) == 0.0 and int(st["done"].sum()) == 0
+    big.reset()
+    out = big.rollout(6, seed=5, step0=0, env0=0, env_total=E)
+    orc = oracle_mod.OracleEnv(E, N, M, poi, 0.2, 0.4, 0.95, 0.0)
+    orc.reset()
+    ref = orc.rollout_rng(6, 5, 0, 0, E, want_obs_last=True)
+    assert np.array_equal(out["done"].cpu().numpy(), ref["done"])
+    np.testing.assert_allclose(out["reward"].cpu().numpy(), ref["reward"], rtol=REW_RTOL, atol=1e-5)
+    assert np.array_equal(out["obs"][-1].cpu().numpy(), ref["obs_last"].astype(np.float32))
+    big.close()
+    small = dcc_hip.HipCoverageEnv(64, N, M, poi, 0.2, 0.4, 0.95, 0.0)
+    assert small.kernel_choice()["choice"] == "default"          # latency-bound sizes are not measured
+    small.close()
+    monkeypatch.setenv("DCC_AUTOTUNE", "0")
+    off = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, 0.4, 0.95, 0.0)
+    assert off.kernel_choice()["choice"] == "default"
+    off.close()
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 0.0, 0.4), (4, 20, 0.0, 0.4), (5, 37, 0.5, 0.2), (16, 256, 0.5, 0.15), (32, 1024, 0.5, 0.1), (3, 130, 0.0, 0.4)],
+                         ids=lambda s: "n%dm%d%s" % (s[0], s[1], "_force" if s[2] else ""))
+@pytest.mark.parametrize("spec", ["spec", "generic"])
+def test_step_features_equals_step_then_features(shape, spec, monkeypatch):
+    """dcc_env_step_features (the step of a policy-driven rollout with structured first layers: one launch that steps the envs
+    AND derives the policy-input features of the state it leaves from the stepping wave's registers) == dcc_env_step
+    followed by dcc_obs_features_x on the emitted state: every per-step output, the emitted state and every feature tensor
+    bit for bit, over a trajectory with auto-resets."""
+    import dcc_hip
+    N, M, cfs, r_comm = shape
+    if spec == "generic" and (N, M) not in ((8, 64), (4, 20), (16, 256)):
+        pytest.skip("no specialised kernel for this size")
+    monkeypatch.setenv("DCC_NO_SPEC", "1" if spec == "generic" else "0")
+    E, T = 96, 40
+    from envs.hip_vec_env import load_pois
+    poi = load_pois(M)
+    a = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, r_comm, 0.95, cfs)
+    b = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, r_comm, 0.95, cfs)
+    a.reset(); b.reset()
+    rng = np.random.RandomState(3)
+    keys = ("reward", "done", "connect", "connect_s", "coverage", "assign", "state_pos", "state_vel", "state_energy", "state_done")
+    mk = lambda env: {**env.alloc_out(obs=False), **env.alloc_state_out()}
+    oa, ob = mk(a), mk(b)
+    fb = b.alloc_features(keys=("head", "poi_feat", "stats", "cstats", "xa", "xc"))
+    resets = 0
+    for t in range(T):
+        scale = 3.0 if t > 20 else 1.0                   # drive some envs out of bounds -> auto-reset
+        act = torch.from_numpy((rng.uniform(-1, 1, (E, N, 2)) * scale).astype(np.float32)).cuda()
+        a.step(act, oa)
+        fa = a.obs_features(oa["state_pos"], oa["state_vel"], oa["state_energy"], oa["state_done"])
+        b.step_features(act, ob, fb)
+        for k in keys:
+            assert torch.equal(oa[k], ob[k]), (k, t)
+        for k in fb:
+            assert torch.equal(fa[k], fb[k]), (k, t)
+        resets += int(oa["done"].sum())
+    assert resets > 0
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    with pytest.raises(ValueError):
+        b.step_features(act, {**ob, "obs": torch.empty(E, N, a.D, device="cuda")}, fb)
+    a.close(); b.close()

@@ -107,7 +107,7 @@ def test_full_size_c3_iteration():
     cfg.update(num_agents=N, num_pois=M, n_rollout_threads=E, n_eval_rollout_threads=0, ppo_epoch=2, save_model=False, n_iters=1)
     lr = Learner(Namespace(**cfg))
     b = lr.rl_buffer
-    assert b.compact and b.structured and b.obs is None and lr.use_hip_graph
+    assert b.compact and b.structured and not torch.is_tensor(b.obs) and lr.use_hip_graph
     p0 = [p.detach().clone() for p in lr.policy.actor.parameters()]
     for it in range(2):                      # eager + capture, then a graph replay
         r = lr.rollout(b, lr.train_envs)

@@ -88,7 +88,7 @@ def test_learner_runs_and_improves_nothing_breaks(tmp_path):
     assert os.path.exists(os.path.join(lr.output_path, "models_2.pt", "agent.pkl"))
     # rollout invariants on the device buffer
     b = lr.rl_buffer
-    assert b.compact and b.structured and b.obs is None       # shipped default: compact env state, no observation rows
+    assert b.compact and b.structured and not torch.is_tensor(b.obs)       # shipped default: compact env state, no observation rows
     assert torch.isfinite(b.returns).all() and torch.isfinite(b.state_pos).all() and torch.isfinite(b.state_energy).all()
     assert bool(((b.masks == 0) | (b.masks == 1)).all())
     # values identical across the agents of an env (centralised critic evaluated once per env)
@@ -380,6 +380,33 @@ def test_hip_graph_rollout_equals_the_eager_rollout():
     ptu.set_gpu_mode(False)
 
 
+def test_rollout_with_step_features_equals_the_two_launch_rollout():
+    """step_features (default on): the env launch of a rollout step also writes the policy-input features of the new state
+    (dcc_env_step_features) and the logged statistics ride in the record launch -- three launches fewer per step than
+    env step + dcc_obs_features + two element-wise torch ops.  Same RNG state -> the same rollout, bit for bit, eagerly and
+    as a replayed graph, and the same update."""
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    for size in (dict(num_agents=4, num_pois=16), dict(num_agents=8, num_pois=64, comm_force_scale=0.5, r_comm=0.2)):
+        kw = dict(n_rollout_threads=32, n_eval_rollout_threads=0, max_ep_len=12, n_iters=1, ppo_epoch=2, algo_hidden_size=32,
+                  save_model=False, seed=23, **size)
+        a, b = Learner(_cfg(**dict(kw, step_features=True))), Learner(_cfg(**dict(kw, step_features=False)))
+        assert a._step_features and not b._step_features and a.rl_buffer.structured and a.rl_buffer.compact
+        for it in range(3):                                   # eager + capture, then replays
+            st = torch.cuda.get_rng_state()
+            ra = a.rollout(a.rl_buffer, a.train_envs)
+            torch.cuda.set_rng_state(st)
+            rb = b.rollout(b.rl_buffer, b.train_envs)
+            assert ra == rb, it
+            for name in ("actions", "action_log_probs", "rewards", "masks", "value_preds", "returns", "state_pos", "state_energy"):
+                assert torch.equal(getattr(a.rl_buffer, name), getattr(b.rl_buffer, name)), (name, it)
+            ia, ib = a.rl_update(), b.rl_update()
+            assert ia == ib and all(np.isfinite(v) for v in ia.values())
+        assert a.rl_buffer._step_feats is not None and b.rl_buffer._step_feats is None
+    ptu.set_gpu_mode(False)
+
+
 def test_compact_state_buffer_trains_like_the_full_buffer():
     """compact_obs: the rollout buffer keeps env state instead of observations and the update regenerates them
     chunk by chunk with dcc_obs_expand.  Same seed -> the same rollout (bit-identical actions/rewards/returns),
@@ -397,7 +424,7 @@ def test_compact_state_buffer_trains_like_the_full_buffer():
     torch.manual_seed(11); r_full = full.rollout(full.rl_buffer, full.train_envs)
     torch.manual_seed(11); r_comp = comp.rollout(comp.rl_buffer, comp.train_envs)
     fb, cb = full.rl_buffer, comp.rl_buffer
-    assert cb.compact and cb.obs is None
+    assert cb.compact and not torch.is_tensor(cb.obs)
     assert r_full == r_comp
     for name in ("actions", "rewards", "masks", "value_preds", "returns", "action_log_probs"):
         assert torch.equal(getattr(fb, name), getattr(cb, name)), name
@@ -429,7 +456,7 @@ def test_structured_input_trains_like_the_full_buffer():
     torch.manual_seed(4)
     r = st.rollout(st.rl_buffer, st.train_envs)
     sb, fb = st.rl_buffer, full.rl_buffer
-    assert sb.structured and sb.compact and sb.obs is None and np.isfinite(r["reward"])
+    assert sb.structured and sb.compact and not torch.is_tensor(sb.obs) and np.isfinite(r["reward"])
     T = sb.episode_length
     fb.obs.copy_(sb.obs_rows(0, T + 1))
     for name in ("actions", "rewards", "masks", "value_preds", "returns", "action_log_probs", "advantages_raw"):
@@ -494,7 +521,7 @@ def test_structured_learner_full_train_loop_with_eval_envs(tmp_path):
     lr = Learner(cfg)
     lr.train()
     assert lr.rl_buffer.structured and lr.test_buffer.structured and len(lr._graphs) == 2
-    assert lr.rl_buffer.obs is not None and not lr.rl_buffer.compact       # compact_obs: false -> features AND rows
+    assert torch.is_tensor(lr.rl_buffer.obs) and not lr.rl_buffer.compact       # compact_obs: false -> features AND rows
     assert os.path.exists(os.path.join(lr.output_path, "models_3.pt", "agent.pkl"))
     lr2 = Learner(_cfg(**dict(vars(cfg), save_model=False, seed=7)))
     lr2.load_checkpoint(os.path.join(lr.output_path, "models_3.pt", "resume.pt"))
