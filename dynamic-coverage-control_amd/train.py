@@ -33,6 +33,8 @@ if __name__ == "__main__":
     overrides = [a for a in sys.argv[1:] if "=" in a]
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         gpu_id = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("DCC_DIST_BACKEND") == "gloo" and torch.cuda.is_available():   # test hook: the ranks may share a GPU
+            gpu_id %= torch.cuda.device_count()
     ptu.set_gpu_mode(torch.cuda.is_available(), gpu_id=gpu_id)
     cfg = load_cfg(overrides)
     print("cuda is available: ", torch.cuda.is_available())

@@ -490,7 +490,7 @@ def test_step_features_equals_step_then_features(shape, spec, monkeypatch):
     if spec == "generic" and (N, M) not in ((8, 64), (4, 20), (16, 256)):
         pytest.skip("no specialised kernel for this size")
     monkeypatch.setenv("DCC_NO_SPEC", "1" if spec == "generic" else "0")
-    E, T = 96, 40
+    E, T = 96, 48
     from envs.hip_vec_env import load_pois
     poi = load_pois(M)
     a = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, r_comm, 0.95, cfs)
@@ -503,8 +503,9 @@ def test_step_features_equals_step_then_features(shape, spec, monkeypatch):
     fb = b.alloc_features(keys=("head", "poi_feat", "stats", "cstats", "xa", "xc"))
     resets = 0
     for t in range(T):
-        scale = 3.0 if t > 20 else 1.0                   # drive some envs out of bounds -> auto-reset
-        act = torch.from_numpy((rng.uniform(-1, 1, (E, N, 2)) * scale).astype(np.float32)).cuda()
+        acts = rng.uniform(-1, 1, (E, N, 2)).astype(np.float32)
+        acts[: E // 2, 0] = (1.0, 0.0)                   # UAV 0 of half the envs flies straight out of bounds -> auto-reset at step 30
+        act = torch.from_numpy(acts).cuda()
         a.step(act, oa)
         fa = a.obs_features(oa["state_pos"], oa["state_vel"], oa["state_energy"], oa["state_done"])
         b.step_features(act, ob, fb)
