@@ -80,6 +80,30 @@ while time.time() - t0 < budget:
         np.testing.assert_allclose(f["stats"][..., 1].cpu().numpy(), ref["stats"][..., 1].cpu().numpy(), rtol=1e-11)
         np.testing.assert_allclose(f["cstats"][:, 0].cpu().numpy(), ref["cstats"][:, 0].cpu().numpy(), rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(f["cstats"][:, 1].cpu().numpy(), ref["cstats"][:, 1].cpu().numpy(), rtol=1e-10)
+        # the rollout step of round 3: ONE launch = env step + features of the state it leaves (dcc_env_step_features) must equal
+        # dcc_env_step followed by dcc_obs_features_x -- every output, the emitted state and every feature tensor bit for bit --
+        # and keep tracking the oracle from the state the case ended in
+        env2 = dcc_hip.HipCoverageEnv(E, N, M, poi, r_cover, r_comm, crs, cfs)
+        env2.set_state(**{kk: v.clone() for kk, v in st.items()})
+        oa = {**env.alloc_out(obs=False), **env.alloc_state_out()}
+        ob = {**env2.alloc_out(obs=False), **env2.alloc_state_out()}
+        fb = env2.alloc_features(keys=("head", "poi_feat", "stats", "cstats", "xa", "xc"))
+        for t2 in range(6):
+            a = np.clip(rs.uniform(-1, 1, (E, N, 2)) * scale + bias, -1, 1).astype(np.float32)
+            at = torch.from_numpy(a).to(env.device)
+            env.step(at, oa)
+            fa = env.obs_features(oa["state_pos"], oa["state_vel"], oa["state_energy"], oa["state_done"])
+            env2.step_features(at, ob, fb)
+            ref = orc.step(a, want_obs=False)
+            for kk in oa:
+                assert torch.equal(oa[kk], ob[kk]), ("step_features output", kk, t2)
+            for kk in fb:
+                assert torch.equal(fa[kk], fb[kk]), ("step_features feature", kk, t2)
+            for kk in ("done", "connect", "connect_s"):
+                assert np.array_equal(ob[kk].cpu().numpy(), ref[kk]), ("step_features vs oracle", kk, t2)
+            assert np.array_equal(ob["assign"].cpu().numpy().astype(np.int32), ref["assign"]), ("step_features assign", t2)
+            steps += E
+        env2.close()
     except Exception as e:  # noqa: BLE001
         print("MISMATCH in case", tag, "->", type(e).__name__, str(e)[:400], flush=True)
         sys.exit(1)

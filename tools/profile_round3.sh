@@ -1,0 +1,90 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): everything profiles/r03/ is built from, in one call on ONE box.
+#   0. which class of box this is: pure-write bandwidth of memset, of the env kernels' own store patterns and of 64 KB chunks
+#      (tools/write_probe2.hip; the boxes of the pool differ by ~12 % in what the same store pattern reaches)
+#   1. the driver's exact bench command (c2 headline + cpu_baseline + c4 / c5 / c3 legs, each with its own cpu_baseline)
+#   2. rocprofv3 --kernel-trace --stats of the same c2 run; the fused kernel for comparison
+#   3. HBM traffic of the env kernel: --pmc WRITE_SIZE / FETCH_SIZE in separate passes + WRITE_SIZE calibration
+#   4. the per-GPU shards of c4 / c5 through the same bench
+#   5. c3: bench.py --mode mappo, update-only split, rollout-only split; the shard sizes through the same learner
+# Output: gpurun_out/profiles_r03/ (copy what is to be kept into profiles/r03/).
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+cd "$R"
+OUT=gpurun_out/profiles_r03
+rm -rf $OUT; mkdir -p $OUT
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/write_probe2.hip -o $OUT/wp2 2> $OUT/wp2_build.err && WP2_QUICK=1 $OUT/wp2 > $OUT/box_class_write_probe.txt 2>&1
+rm -f $OUT/wp2
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err
+C2="python bench.py --steps 20 --warmup 5 --no-c3 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $C2 > $OUT/bench_under_trace.json 2> $OUT/trace.err
+cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats_bench_default.csv 2>/dev/null; rm -rf $OUT/trace
+DCC_NO_ROLES=1 $C2 > $OUT/bench_fused_kernel.json 2>/dev/null
+PM="python bench.py --steps 1 --warmup 1 --launches-per-step 4 --no-c3 --no-cpu-baseline"
+for C in WRITE_SIZE FETCH_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- $PM > /dev/null 2> $OUT/pmc_$C.err
+  python tools/pmc_summary.py $OUT/pmc_$C 150 > $OUT/pmc_$C.txt 2>&1
+  rm -rf $OUT/pmc_$C $OUT/pmc_$C.err
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/membw.hip -o $OUT/membw 2> $OUT/membw_build.err && {
+  $OUT/membw > $OUT/membw_fill_copy.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_cal -- $OUT/membw > /dev/null 2> $OUT/pmc_cal.err
+  python - <<'PY' > $OUT/pmc_WRITE_SIZE_calibration.txt
+import csv, glob, collections
+f = glob.glob('gpurun_out/profiles_r03/pmc_cal/**/*_counter_collection.csv', recursive=True)[0]
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if r['Counter_Name'] == 'WRITE_SIZE':
+        acc[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+known = 150 * 4096 * 676 * 16
+for k, v in acc.items():
+    per = sum(v) / len(v)
+    if k.strip() in ('fill4', 'copy4', 'wave_blocks'):
+        print("%-12s launches=%d  WRITE_SIZE=%.6g (KB units) -> %.4f GB per launch; known bytes written %.4f GB; calibration factor (known / counted) = %.4f"
+              % (k.strip(), len(v), per, per * 1024 / 1e9, known / 1e9, known / (per * 1024)))
+PY
+  rm -rf $OUT/pmc_cal $OUT/membw $OUT/pmc_cal.err
+}
+python - <<'PY'
+import json, re
+out = 'gpurun_out/profiles_r03/'
+def per_launch(name):
+    for l in open(out + name):
+        m = re.search(r'total=([0-9.e+]+)', l)
+        if m and 'n=' in l:
+            return float(m.group(1))
+    return None
+w, f = per_launch('pmc_WRITE_SIZE.txt'), per_launch('pmc_FETCH_SIZE.txt')
+cal = 1.0
+try:
+    for l in open(out + 'pmc_WRITE_SIZE_calibration.txt'):
+        if l.startswith('wave_blocks'):
+            cal = float(l.rsplit('=', 1)[1])
+except Exception:
+    pass
+if w is not None and f is not None:
+    wb, fb = w * 1024 * cal, f * 1024 * 2
+    json.dump({"workload": {"n_agents": 8, "n_pois": 64, "envs": 4096, "steps_per_launch": 150, "actions": "hbm"},
+               "write_bytes_per_launch": wb, "write_size_calibration_factor": cal, "fetch_bytes_per_launch_corrected_x2": fb,
+               "traffic_bytes_per_launch": wb + fb, "algorithmic_bytes_per_launch": 11851 * 4096 * 150,
+               "source": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes, KB units x1024; WRITE_SIZE calibrated on the "
+                         "known byte count of tools/membw.hip's wave_blocks store pattern, FETCH_SIZE doubled per MI355X_MICROARCH.md's "
+                         "gfx950 note), profiles/r03/pmc_WRITE_SIZE.txt, pmc_FETCH_SIZE.txt, pmc_WRITE_SIZE_calibration.txt"},
+              open(out + 'traffic_c2.json', 'w'), indent=1)
+PY
+# --- the per-GPU shards of c4 / c5 (the shapes an 8-GPU job runs) and the c1 size
+python bench.py --agents 16 --pois 256 --envs 1024 --steps 5 --warmup 2 --launches-per-step 8 --no-c3 --no-cpu-baseline > $OUT/bench_c4_shard.json 2>/dev/null
+DCC_NO_SPLIT=1 python bench.py --agents 16 --pois 256 --envs 1024 --steps 5 --warmup 2 --launches-per-step 8 --no-c3 --no-cpu-baseline > $OUT/bench_c4_shard_fused_kernel.json 2>/dev/null
+python bench.py --agents 32 --pois 1024 --envs 2048 --comm-force-scale 0.5 --r-comm 0.1 --steps-per-launch 50 --steps 3 --warmup 1 --launches-per-step 2 --no-c3 --no-cpu-baseline > $OUT/bench_c5_shard.json 2>/dev/null
+python bench.py --agents 4 --pois 16 --steps 5 --warmup 2 --no-c3 --no-cpu-baseline > $OUT/bench_c1_size.json 2>/dev/null
+# --- c3
+python bench.py --mode mappo --iters 3 2>/dev/null | tail -1 > $OUT/mappo_c3_default.json
+python bench.py --mode mappo --iters 3 --agents 16 --pois 256 --envs 1024 2>/dev/null | tail -1 > $OUT/mappo_c4_shard.json
+python bench.py --mode mappo --iters 2 --agents 32 --pois 1024 --envs 2048 --comm-force-scale 0.5 --r-comm 0.1 2>/dev/null | tail -1 > $OUT/mappo_c5_full_shard.json
+tools/profile_update_only.sh > $OUT/mappo_c3_update_only.txt 2>&1
+tools/profile_rollout_only.sh > $OUT/mappo_c3_rollout_only.txt 2>&1
+tools/profile_rollout_only.sh --agents 32 --pois 1024 --envs 2048 --comm-force-scale 0.5 --r-comm 0.1 > $OUT/mappo_c5_shard_rollout_only.txt 2>&1
+python tools/fuzz_env_parity.py 150 20260928 > $OUT/fuzz_env_parity.txt 2>&1
+ls -la $OUT
+cat $OUT/box_class_write_probe.txt $OUT/traffic_c2.json

@@ -60,9 +60,11 @@ int main() {
     printf("hipMemsetAsync   %6.0f GB/s\n", timeit([&] { CK(hipMemsetAsync(a, 0, bytes, 0)); }, bytes));
     printf("== K-step env structure: K=150 steps; block bytes per env-step, envs, envs per writer (G), waves per writer (team) -> GB/s\n");
     struct Cfg { int K, E; size_t blk; } cfgs[] = {{150, 4096, 10816}, {75, 1024, 84096}, {4, 2048, 663808}};   // each <= 6.6 GB
+    const bool quick = getenv("WP2_QUICK") != nullptr;     // box classification only: the kernels' own patterns + memset + 64 KB chunks
     for (auto c : cfgs)
         for (int G : {1, 2, 3, 4, 6, 8, 12, 16})
             for (int team : {1, 2, 4}) {
+                if (quick && !((c.blk == 10816 && G == 2 && team == 1) || (c.blk != 10816 && G == 1 && team != 2))) continue;
                 if (c.blk > 100000 && G > 2) continue;
                 if (c.blk > 50000 && G > 4) continue;
                 const int writers = c.E / G, waves = writers * team;
@@ -78,6 +80,7 @@ int main() {
     for (size_t cb : chunks)
         for (int team : {1, 4})
             for (int waves : {2048, 4096}) {
+                if (quick && !(cb == 65536 && team == 1)) continue;
                 const int grid = waves / 4;
                 const size_t used = (n4 / (cb / 16)) * cb;
                 printf("chunk=%7zu team=%d waves=%4d  %6.0f | %6.0f\n", cb, team, waves,
