@@ -1030,7 +1030,11 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? (PPL >= 4 ? 2 : 3)
 // energies, done mask: ~0.5 KB) to wave 1 through a double-buffered LDS slot; wave 1 expands it into the
 // observation rows and streams them to HBM.  ready/consumed counters in LDS (workgroup-scope release/acquire)
 // let the physics wave run up to two steps ahead, so the observation wave always has a backlog.
-constexpr int kRolesBlock = 128;   // wave 0 = physics, wave 1 = observation (a second wave of either kind did not help)
+#ifndef DCC_ROLES_OBS
+#define DCC_ROLES_OBS 1            // observation waves per workgroup: 1 = one wave streams both envs as ONE stream; 2 = one wave per env
+#endif
+constexpr int kRolesObs = DCC_ROLES_OBS;
+constexpr int kRolesBlock = 64 * (1 + kRolesObs);   // wave 0 = physics, waves 1.. = observation
 struct Handoff {  // one env, one slot; laid out in LDS as: apos[N] | avel[N] | en[64] | dmask(u64) | pad | StepRec
     double2* apos; double2* avel; float* en; unsigned long long* dmask; StepRec* rec;
 };
@@ -1069,7 +1073,7 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
     const int hb = handoff_bytes(N);
     unsigned char* hbase = smem + ((M * 16 + 15) & ~15);
     unsigned* flags = reinterpret_cast<unsigned*>(hbase + 4 * hb);
-    float* stg = reinterpret_cast<float*>(hbase + 4 * hb + 16);
+    float* stg = reinterpret_cast<float*>(hbase + 4 * hb + 16) + (role > 1 ? (role - 1) * kStageC : 0);
 
     for (int j = threadIdx.x; j < M; j += kRolesBlock) s_poi[j] = p.poi[j];
     if (threadIdx.x < 4) flags[threadIdx.x] = 0u;
@@ -1130,6 +1134,7 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
             for (int s = 0; s < 2; ++s) {
                 const int env = env_base + s;
                 if (env >= p.E) continue;
+                if (kRolesObs == 2 && s != role - 1) continue;       // one observation wave per env
                 spin_until_ge(&flags[s], (unsigned)(k + 1));
                 Handoff h = handoff_at(hbase + (2 * s + (k & 1)) * hb, N);
                 float en[1];
@@ -1142,7 +1147,7 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
                     // The assignment rows of the workgroup's two envs are adjacent in HBM (2 x M bytes): with one
                     // observation wave they are written by ONE store (a full 128-byte line at M = 64) instead of
                     // two half-line stores a microsecond apart.
-                    const bool pair = (M & 3) == 0 && p.assign != nullptr;
+                    const bool pair = kRolesObs == 1 && (M & 3) == 0 && p.assign != nullptr;
                     if (pair) {
                         const int nd = M >> 2;   // dwords per row (<= 16)
                         const int t1 = am[0] | (__builtin_amdgcn_update_dpp(0, am[0], 0xF9, 0xF, 0xF, false) << 8);
@@ -1169,10 +1174,15 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
                         if (p.st_done) p.st_done[ko * M + lane] = (uint8_t)dmask;
                     }
                 }
-                // both envs of the workgroup: one output stream of 2 L floats
-                if (s == 0) { st.w0 = 0; st.gout = p.obs + ((size_t)k * p.E + env_base) * (size_t)L; }
-                produce_obs<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane,
-                                                s * L, (s == 1) || (env_base + 1 >= p.E));
+                if (kRolesObs == 2) {   // own block, own stream
+                    st.w0 = 0; st.gout = p.obs + ((size_t)k * p.E + env) * (size_t)L;
+                    produce_obs<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane, 0, true);
+                } else {
+                    // both envs of the workgroup: one output stream of 2 L floats
+                    if (s == 0) { st.w0 = 0; st.gout = p.obs + ((size_t)k * p.E + env_base) * (size_t)L; }
+                    produce_obs<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane,
+                                                    s * L, (s == 1) || (env_base + 1 >= p.E));
+                }
                 publish(&flags[2 + s], (unsigned)(k + 1), lane);
             }
         }
@@ -1678,7 +1688,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     { const char* fr = std::getenv("DCC_FORCE_ROLES"); e->force_roles = fr && fr[0] == '1'; }
     { const char* ns = std::getenv("DCC_NO_SPLIT"); e->no_split = ns && ns[0] == '1'; }
     { const char* fs = std::getenv("DCC_FORCE_SPLIT"); e->force_split = fs && fs[0] == '1'; }
-    e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kStageC * 4;
+    e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kRolesObs * kStageC * 4;
     e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);
     e->lds_bytes_split = (size_t)((M * 16 + 15) & ~15) + 2 * ((size_t)N * 32 + (size_t)p2 * 256 + 256) + 16 +
                          (size_t)kSplitObs * kStageC * 4;
