@@ -63,6 +63,7 @@ class HipCoverageVecEnv:
         self.poi_xy = poi
         self.env = dcc_hip.HipCoverageEnv(self.n_envs, self.n_agents, self.n_pois, poi, r_cover, r_comm, comm_r_scale,
                                           comm_force_scale, device=device, **consts)
+        self._render_consts = dict(r_cover=r_cover, r_comm=r_comm)
         self.device = self.env.device
         self.obs_dim = self.env.D
         self.env0, self.env_total = env0, (env_total or self.n_envs)   # position of this shard in a multi-GPU job
@@ -149,8 +150,22 @@ class HipCoverageVecEnv:
         a, self._pending = self._pending, None
         return self.step(a)
 
-    def render(self, mode="human"):
-        raise NotImplementedError("rendering (pyglet viewer of the reference) is out of scope; use get_state()")
+    RENDER_MAX_ENVS = 16
+
+    def render(self, mode="human", size=350):
+        """wrappers.py:196-201,254-259.  There is no display on a GPU node: "human" is a no-op (the reference opens a pyglet
+        window), "rgb_array" returns headless frames [n, 1, size, size, 3] uint8 of the first n = min(n_envs, 16) envs
+        (envs/render.py), indexed like the reference's (`frame[0][0]` = the image of env 0, learner.py:199-200)."""
+        if mode == "human":
+            return None
+        if mode != "rgb_array":
+            raise NotImplementedError("render mode %r" % (mode,))
+        from envs.render import rasterize
+        n = min(self.n_envs, self.RENDER_MAX_ENVS)
+        st = {k: v[:n].cpu().numpy() for k, v in self.env.get_state().items()}
+        c = self._render_consts
+        return np.stack([rasterize(st["pos"][e], self.poi_xy, st["energy"][e], st["done"][e], c["r_cover"], self.env.m_energy,
+                                   c["r_comm"], size)[None] for e in range(n)])
 
     def get_state(self):
         return {k: v.cpu().numpy() for k, v in self.env.get_state().items()}

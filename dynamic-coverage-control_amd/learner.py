@@ -100,6 +100,17 @@ class Learner:
             self.test_envs = make_env(tcfg)
             self.test_buffer = self._make_buffer(self.test_envs)
 
+        # render rollouts (reference learner.py:80-91,148-149,195-210): headless frames -> an animated GIF per render_interval.
+        # Only built when GIFs are asked for (save_gifs): without a display the frames have no other consumer.
+        self.render_envs = self.render_buffer = None
+        self.save_gifs = bool(getattr(self.cfg, "save_gifs", False))
+        if self.save_gifs and int(getattr(self.cfg, "n_render_rollout_threads", 0)) > 0:
+            rcfg = copy.deepcopy(self.cfg)
+            rcfg.n_rollout_threads = self.world * int(self.cfg.n_render_rollout_threads)
+            self.render_envs = make_env(rcfg)
+            self.render_buffer = self._make_buffer(self.render_envs)
+        self.render_interval = int(getattr(self.cfg, "render_interval", 10 ** 9))
+
         # 4. loop parameters
         self.use_linear_lr_decay = self.cfg.use_linear_lr_decay
         self.n_iters = self.cfg.n_iters
@@ -149,6 +160,8 @@ class Learner:
             test_rollout_info = {}
             if self.test_envs is not None and iter_ % self.eval_interval == 0:
                 test_rollout_info = self.rollout(self.test_buffer, self.test_envs)
+            if self.render_envs is not None and iter_ % self.render_interval == 0:
+                self.rollout(self.render_buffer, self.render_envs, is_render=True, iter_=iter_)
             if iter_ % self.log_interval == 0:
                 self.log(iter_=iter_, rollout_info=rollout_info, rl_train_info=rl_train_info,
                          test_rollout_info=test_rollout_info)
@@ -160,11 +173,14 @@ class Learner:
         self.train_envs.close()
         if self.test_envs is not None:
             self.test_envs.close()
+        if self.render_envs is not None:
+            self.render_envs.close()
 
     # ---- rollout (learner.py:178-214) -------------------------------------------------------------------
     @torch.no_grad()
-    def _rollout_body(self, r_buffer, r_envs):
-        """warmup + T x (collect -> env step -> insert) + compute, all asynchronous on the current stream."""
+    def _rollout_body(self, r_buffer, r_envs, frames=None):
+        """warmup + T x (collect -> env step -> insert) + compute, all asynchronous on the current stream.
+        frames: a list that receives one headless frame of env 0 per step (render rollouts: learner.py:195-200)."""
         self.warmup(r_buffer, r_envs)
         rew_acc = torch.zeros(r_envs.n_envs, dtype=torch.float64, device=ptu.device)    # per env: element-wise only
         cov_max = torch.zeros(r_envs.n_envs, dtype=torch.float32, device=ptu.device)
@@ -190,8 +206,12 @@ class Learner:
                 dcc_hip.rollout_record(out["reward"], out["done"], r_buffer.rewards[cur_step], r_buffer.masks[cur_step + 1],
                                        self.n_agents, coverage=out["coverage"], rew_acc=rew_acc, cov_max=cov_max)   # + the logged statistics
                 r_buffer.step = (cur_step + 1) % r_buffer.episode_length
+                if frames is not None:
+                    frames.append(r_envs.render("rgb_array")[0][0])
                 continue
             self.insert((out, values, actions, action_log_probs, rnn_a, rnn_c), r_buffer)
+            if frames is not None:
+                frames.append(r_envs.render("rgb_array")[0][0])
             rew_acc += out["reward"]
             cov_max = torch.maximum(cov_max, out["coverage"])
         self.compute(r_buffer)
@@ -199,14 +219,18 @@ class Learner:
 
     @torch.no_grad()
     def rollout(self, r_buffer, r_envs, is_render=False, iter_=0):
-        if is_render:
-            raise NotImplementedError("rendering is out of scope (no display on a GPU node)")
         key = id(r_buffer)
         r_buffer.invalidate_features()     # host-side cache: must also be dropped when the rollout is a graph replay
         if r_buffer.structured:            # parameter-derived inference tensors the (captured) rollout reads
             from algos.algo_utils.structured import refresh_folded_weights
             refresh_folded_weights(self.policy.actor, self.policy.critic)
-        if self.use_hip_graph and key in self._graphs:
+        if is_render:      # eager, one frame per step; the GIF lands where the reference puts it (learner.py:204-210)
+            frames = []
+            stats = self._rollout_body(r_buffer, r_envs, frames)
+            if self.save_gifs and self.is_save_model and self.rank == 0 and frames:
+                from envs.render import save_gif
+                save_gif(frames, os.path.join(self.output_path, "models_%d.gif" % iter_), float(getattr(self.cfg, "ifi", 0.1)))
+        elif self.use_hip_graph and key in self._graphs:
             graph, stats = self._graphs[key]
             graph.replay()
         else:
