@@ -186,7 +186,9 @@ DCC_API int dcc_env_step_features(dcc_env* env, const void* actions, int act_dty
 DCC_API int64_t dcc_env_bytes_per_step(int32_t n_agents, int32_t n_pois, int32_t with_actions, int32_t with_obs);
 
 /* Which kernel shape obs-writing multi-step launches of this env use, as measured by dcc_env_create on THIS device (a short
- * rollout through each shape; batches of >= 8 MB of observation rows per step with <= 64 PoIs; DCC_AUTOTUNE=0 disables):
+ * rollout of 64 steps through each shape into a scratch buffer; batches of >= 8 MB of observation rows per step with <= 64 PoIs;
+ * the fused shape is taken only when it is more than 6 % ahead, the margin covering the role-specialised shape's pipeline fill
+ * in a short launch; DCC_AUTOTUNE=0 disables):
  * returns 0 = not measured (the built-in default applies), 1 = role-specialised (a physics wave + an observation wave per
  * two envs), 2 = fused (one wave per env); the measured microseconds per batched step go to us_roles / us_fused (may be
  * NULL).  Both shapes produce bit-identical outputs. */

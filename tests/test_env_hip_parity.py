@@ -456,7 +456,7 @@ def test_kernel_shape_is_measured_at_create_and_both_shapes_agree(oracle_mod, mo
     big = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, 0.4, 0.95, 0.0)
     kc = big.kernel_choice()
     assert kc["choice"] in ("roles", "fused") and kc["us_per_step_roles"] > 0 and kc["us_per_step_fused"] > 0
-    assert (kc["choice"] == "fused") == (kc["us_per_step_fused"] < 0.985 * kc["us_per_step_roles"])
+    assert (kc["choice"] == "fused") == (kc["us_per_step_fused"] < 0.94 * kc["us_per_step_roles"])
     st = big.get_state()        # the measurement leaves the state dcc_env_create promises: every env at reset
     assert float(st["pos"].abs().sum()) == 0.0 and float(st["energy"].abs().sum()) == 0.0 and int(st["done"].sum()) == 0
     big.reset()
