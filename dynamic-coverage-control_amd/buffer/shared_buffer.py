@@ -113,6 +113,8 @@ class _Rows(object):
         # else: share_obs is a view of obs; the rows written to `obs` carry it
 
     def __getattr__(self, name):
+        if name.startswith("__"):        # copy / pickle / hasattr probes must see a plain AttributeError
+            raise AttributeError(name)
         return getattr(self._full(), name)
 
 
