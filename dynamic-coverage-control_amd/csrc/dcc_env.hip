@@ -1084,6 +1084,9 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
 
     if (role == 0) {
         // ---------------- physics wave: both envs of the workgroup, up to two steps ahead -------------------
+#ifdef DCC_ROLES_PHYS_PRIO
+        __builtin_amdgcn_s_setprio(DCC_ROLES_PHYS_PRIO);
+#endif
         EnvRegs<PPL> r[2];
         ActFetch<act_rf<PPL, FORCE>()> af[2];
 #pragma unroll
@@ -1125,7 +1128,10 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
     } else {
         // ---------------- observation wave: expand + stream, one env-step at a time ---------------------------
         // It is the wave that feeds HBM: it outranks the physics waves on its SIMD (they have slack).
-        __builtin_amdgcn_s_setprio(3);
+#ifndef DCC_ROLES_OBS_PRIO
+#define DCC_ROLES_OBS_PRIO 3
+#endif
+        __builtin_amdgcn_s_setprio(DCC_ROLES_OBS_PRIO);
         unsigned assign_w0 = 0;   // env 0's packed assignment row, held until env 1's is ready
         Stager st;
         st.stg = stg; st.w0 = 0; st.vec = SPEC ? 1 : p.vec_ok; st.gout = p.obs;
@@ -1278,6 +1284,13 @@ __global__ __launch_bounds__(kSplitBlock, (PPL >= 8 || FORCE ? 1 : 2)) void dcc_
     poi.init(s_poi, lane, M);
 
     if (role == 0) {
+        // The physics wave is the producer every observation wave of the workgroup waits for: it outranks them (it blocks on
+        // the slot flags after running two steps ahead, so it cannot hog the SIMD).  Same-box A/B at the c4 shard, well-placed
+        // output buffer: 2.297 vs 2.372 ms per 150-step launch with the priorities the other way round (round 3).
+#ifndef DCC_SPLIT_PHYS_PRIO
+#define DCC_SPLIT_PHYS_PRIO 3
+#endif
+        __builtin_amdgcn_s_setprio(DCC_SPLIT_PHYS_PRIO);
         EnvRegs<PPL> r;
         ActFetch<act_rf<PPL, FORCE>()> af;
         init_act(af);
@@ -1304,7 +1317,10 @@ __global__ __launch_bounds__(kSplitBlock, (PPL >= 8 || FORCE ? 1 : 2)) void dcc_
         }
         store_env_state<PPL>(p, env, lane, N, M, r);
     } else {
-        __builtin_amdgcn_s_setprio(3);
+#ifndef DCC_SPLIT_OBS_PRIO
+#define DCC_SPLIT_OBS_PRIO 1
+#endif
+        __builtin_amdgcn_s_setprio(DCC_SPLIT_OBS_PRIO);
         const int w = role - 1;
         const int vec = SPEC ? 1 : p.vec_ok;
         // contiguous row ranges whose first float index i0 * D is a multiple of 4 in float4 mode
@@ -1751,8 +1767,9 @@ int dcc_env_reset(dcc_env* e, float* obs, void* stream) {
     return launch(e, p, 0, stream);
 }
 
-// Profiling aid (not in the public header): K repetitions of the observation producer only
-// (reset state, no physics) -- isolates the LDS staging + HBM store pipeline.
+// K repetitions of the observation producer only (reset state, no physics): the env kernels' own store pattern -- isolates
+// the LDS staging + HBM store pipeline, and is what dcc_env_obs_write_probe times to tell a well-placed output buffer from
+// a badly placed one.
 __attribute__((visibility("default"))) int dcc_debug_obs_only(dcc_env* e, int32_t K, float* obs, void* stream) {
     if (!e || K < 1) return fail(DCC_EINVAL, "dcc_debug_obs_only: bad argument");
     DeviceGuard guard(e->device);
@@ -1763,6 +1780,11 @@ __attribute__((visibility("default"))) int dcc_debug_obs_only(dcc_env* e, int32_
     o.obs = obs;
     fill_out(p, &o);
     return launch(e, p, 0, stream);
+}
+
+int dcc_env_obs_write_probe(dcc_env* e, int32_t K, float* obs, void* stream) {
+    if (!obs) return fail(DCC_EINVAL, "dcc_env_obs_write_probe: obs is NULL");
+    return dcc_debug_obs_only(e, K, obs, stream);
 }
 
 int dcc_env_step(dcc_env* e, const void* actions, int act_dtype, const dcc_env_out* out, void* stream) {

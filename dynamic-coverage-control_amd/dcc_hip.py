@@ -45,7 +45,7 @@ class ObsFeat(ctypes.Structure):       # include/dcc_env.h: dcc_obs_feat
 
 
 EXPORTS = ["dcc_obs_expand", "dcc_gae_compute", "dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
-           "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_step_features", "dcc_env_rollout", "dcc_env_get_state",
+           "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_step_features", "dcc_env_obs_write_probe", "dcc_env_rollout", "dcc_env_get_state",
            "dcc_env_set_state", "dcc_env_bytes_per_step", "dcc_env_kernel_choice", "dcc_obs_features", "dcc_obs_features_x",
            "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_relu_ln_head_fwd", "dcc_relu_ln_head_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd", "dcc_actor_l1_pre_fwd", "dcc_actor_l1_pre_bwd",
            "dcc_ppo_policy_loss",
@@ -81,6 +81,7 @@ def load_library(path=None):
     L.dcc_env_bytes_per_step.argtypes = [ctypes.c_int32] * 4
     L.dcc_env_bytes_per_step.restype = ctypes.c_int64
     L.dcc_env_kernel_choice.argtypes = [_vp, _vp, _vp]
+    L.dcc_env_obs_write_probe.argtypes = [_vp, ctypes.c_int32, _vp, _vp]
     L.dcc_env_step_features.argtypes = [_vp, _vp, ctypes.c_int, ctypes.POINTER(EnvOut), ctypes.POINTER(ObsFeat), _vp]
     L.dcc_gae_compute.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, ctypes.c_int32,
                                   ctypes.c_int64, _vp]
@@ -180,13 +181,60 @@ class HipCoverageEnv:
             raise DccError("dcc_env_kernel_choice failed (%d): %s" % (rc, load_library().dcc_last_error().decode()))
         return {"choice": {0: "default", 1: "roles", 2: "fused"}[rc], "us_per_step_roles": a.value, "us_per_step_fused": b.value}
 
-    def alloc_out(self, K=None, obs=True, assign=True, reward64=False):
+    PLACE_MIN_BYTES = 256 << 20     # buffers below this are not worth placing
+
+    def alloc_placed_obs(self, K, tries=6):
+        """An observation buffer [K, E, N, D] for MANY fused launches, placed well.  Where a buffer lies in HBM decides how fast
+        the env kernels' store pattern streams into it: the same launch runs 6-8 % slower into some allocations than into
+        others of the same process, reproducibly per buffer (tools/placement_probe.py; a sequential memset does not care, so
+        this is about the scattered-chunk pattern, not about the memory).  Up to `tries` candidate allocations are timed with
+        dcc_env_obs_write_probe (the observation producer alone over the WHOLE buffer, 3 launches: a buffer can be fast in one
+        part and slow in another) while the earlier ones
+        stay allocated, the fastest is kept and the others go back to the allocator; stops early once a candidate is clearly in
+        the fast mode (>= 4 % ahead of the slowest seen).  RESETS the env state (call before the first step).
+        Returns (tensor, info) with info = {"tried", "probe_ms", "chosen"}."""
+        shape = (K, self.E, self.N, self.D)
+        kp = K
+        cands, times = [], []
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        with torch.cuda.device(self.device):
+            for i in range(max(1, tries)):
+                try:
+                    t = torch.empty(shape, dtype=torch.float32, device=self.device)
+                except torch.cuda.OutOfMemoryError:
+                    break
+                best = None
+                for rep in range(4):        # rep 0 warms up (first touch)
+                    a, b = ev(), ev()
+                    a.record()
+                    _check(self.lib.dcc_env_obs_write_probe(self._h, kp, _ptr(t), _stream()), "dcc_env_obs_write_probe")
+                    b.record(); b.synchronize()
+                    ms = a.elapsed_time(b)
+                    if rep and (best is None or ms < best):
+                        best = ms
+                cands.append(t); times.append(best)
+                if len(times) >= 2 and best <= 0.96 * max(times):
+                    break
+        if not cands:
+            raise RuntimeError("alloc_placed_obs: out of memory")
+        k = min(range(len(times)), key=times.__getitem__)
+        keep = cands[k]
+        del cands
+        return keep, {"tried": len(times), "probe_ms": [round(x, 4) for x in times], "chosen": k, "probe_steps": kp}
+
+    def alloc_out(self, K=None, obs=True, assign=True, reward64=False, placed=0):
+        """Output tensors of step() (K None) / rollout(K).  placed = n > 0 (rollout buffers of >= 256 MB only): the observation
+        buffer is the best-placed of up to n candidate allocations (alloc_placed_obs; resets the env state) and
+        `self.placement_info` says what was tried."""
         lead = () if K is None else (K,)
         mk = lambda shape, dt: torch.empty(lead + shape, dtype=dt, device=self.device)
         out = dict(reward=mk((self.E,), torch.float32), done=mk((self.E,), torch.uint8),
                    connect=mk((self.E,), torch.uint8), connect_s=mk((self.E,), torch.uint8),
                    coverage=mk((self.E,), torch.float32))
-        if obs:
+        self.placement_info = None
+        if obs and placed and K and K * self.E * self.N * self.D * 4 >= self.PLACE_MIN_BYTES:
+            out["obs"], self.placement_info = self.alloc_placed_obs(K, placed)
+        elif obs:
             out["obs"] = mk((self.E, self.N, self.D), torch.float32)
         if assign:
             out["assign"] = mk((self.E, self.M), torch.uint8)

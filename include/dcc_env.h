@@ -185,6 +185,14 @@ DCC_API int dcc_env_step_features(dcc_env* env, const void* actions, int act_dty
  * 40N + 11M + 11 + 4*N*D; with_actions=0 drops 8N; with_obs=0 drops 4*N*D. */
 DCC_API int64_t dcc_env_bytes_per_step(int32_t n_agents, int32_t n_pois, int32_t with_actions, int32_t with_obs);
 
+/* The observation producer alone, K times from the reset state into obs [K, E, N, D] (no physics, no other output): the env
+ * kernels' own store pattern.  Purpose: WHERE an output buffer lies in HBM decides how fast this pattern streams into it -- the
+ * same 150-step launch takes 1.20 ms into one 6.6 GB buffer and 1.28 ms into another one of the same process, reproducibly per
+ * buffer, while a sequential memset is indifferent (tools/placement_probe.py) -- so a caller that is about to stream many
+ * launches into one buffer can time this call on a few candidate allocations and keep the best (dcc_hip.py:
+ * HipCoverageEnv.alloc_out(placed=...)).  RESETS the env state (like dcc_env_reset); asynchronous on `stream`. */
+DCC_API int dcc_env_obs_write_probe(dcc_env* env, int32_t K, float* obs, void* stream);
+
 /* Which kernel shape obs-writing multi-step launches of this env use, as measured by dcc_env_create on THIS device (a short
  * rollout of 64 steps through each shape into a scratch buffer; batches of >= 8 MB of observation rows per step with <= 64 PoIs;
  * the fused shape is taken only when it is more than 6 % ahead, the margin covering the role-specialised shape's pipeline fill

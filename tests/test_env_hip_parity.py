@@ -521,3 +521,32 @@ def test_step_features_equals_step_then_features(shape, spec, monkeypatch):
     with pytest.raises(ValueError):
         b.step_features(act, {**ob, "obs": torch.empty(E, N, a.D, device="cuda")}, fb)
     a.close(); b.close()
+
+
+def test_placed_observation_buffer_is_just_a_buffer(oracle_mod):
+    """alloc_out(K, placed=n): the observation buffer of a rollout is the best of up to n candidate allocations, timed with
+    dcc_env_obs_write_probe (where a buffer lies in HBM decides how fast the env kernels' store pattern streams into it:
+    tools/placement_probe.py).  It must be nothing but a buffer: same shape / dtype, the env left in the reset state, and a
+    rollout into it equals the oracle's; small buffers are not placed."""
+    import dcc_hip
+    E, N, M, K = 2048, 8, 64, 24          # 532 MB of rows: above the placing threshold
+    poi = np.load(os.path.join(os.path.dirname(__file__), "golden", "pos_pois.npy"))[:M]
+    env = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, 0.4, 0.95, 0.0)
+    env.reset()
+    env.rollout(3, seed=1, env0=0, env_total=E)                      # leave the reset state ...
+    out = env.alloc_out(K, placed=3)
+    info = env.placement_info
+    assert info is not None and 1 <= info["tried"] <= 3 and len(info["probe_ms"]) == info["tried"] and min(info["probe_ms"]) > 0
+    assert info["probe_ms"][info["chosen"]] == min(info["probe_ms"])
+    assert tuple(out["obs"].shape) == (K, E, N, env.D) and out["obs"].dtype == torch.float32 and out["obs"].is_contiguous()
+    st = env.get_state()                                             # ... the probe put it back there
+    assert float(st["pos"].abs().sum()) == 0.0 and float(st["energy"].abs().sum()) == 0.0
+    env.rollout(K, seed=9, step0=0, env0=0, env_total=E, out=out)
+    orc = oracle_mod.OracleEnv(E, N, M, poi, 0.2, 0.4, 0.95, 0.0)
+    orc.reset()
+    ref = orc.rollout_rng(K, 9, 0, 0, E, want_obs_last=True)
+    assert np.array_equal(out["done"].cpu().numpy(), ref["done"])
+    assert np.array_equal(out["obs"][-1].cpu().numpy(), ref["obs_last"].astype(np.float32))
+    small = env.alloc_out(2, placed=3)
+    assert env.placement_info is None and tuple(small["obs"].shape) == (2, E, N, env.D)
+    env.close()
