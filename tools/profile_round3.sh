@@ -21,7 +21,9 @@ C2="python bench.py --steps 20 --warmup 5 --no-c3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $C2 > $OUT/bench_under_trace.json 2> $OUT/trace.err
 cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats_bench_default.csv 2>/dev/null; rm -rf $OUT/trace
 DCC_NO_ROLES=1 $C2 > $OUT/bench_fused_kernel.json 2>/dev/null
-PM="python bench.py --steps 1 --warmup 1 --launches-per-step 4 --no-c3 --no-cpu-baseline"
+# only the 8 timed / warm-up launches may reach the counters: no create-time shape measurement, no placement probes
+export DCC_AUTOTUNE_SAVED=${DCC_AUTOTUNE:-}
+PM="env DCC_AUTOTUNE=0 python bench.py --steps 1 --warmup 1 --launches-per-step 4 --no-c3 --no-cpu-baseline --place-tries 0"
 for C in WRITE_SIZE FETCH_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- $PM > /dev/null 2> $OUT/pmc_$C.err
   python tools/pmc_summary.py $OUT/pmc_$C 150 > $OUT/pmc_$C.txt 2>&1
