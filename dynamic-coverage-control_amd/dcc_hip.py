@@ -195,6 +195,9 @@ class HipCoverageEnv:
         Returns (tensor, info) with info = {"tried", "probe_ms", "chosen"}."""
         shape = (K, self.E, self.N, self.D)
         kp = K
+        nbytes = K * self.E * self.N * self.D * 4
+        free = torch.cuda.mem_get_info(self.device)[0]
+        tries = max(1, min(int(tries), int(0.5 * free // max(1, nbytes))))     # the candidates are all alive at once: at most half of what is free
         cands, times = [], []
         ev = lambda: torch.cuda.Event(enable_timing=True)
         with torch.cuda.device(self.device):
