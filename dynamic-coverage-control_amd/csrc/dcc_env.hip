@@ -1308,7 +1308,11 @@ __global__ __launch_bounds__(kSplitBlock, (PPL >= 8 || FORCE ? 1 : 2)) void dcc_
 #pragma unroll
                 for (int w = 0; w < kSplitObs; ++w) spin_until_ge(&flags[1 + w], (unsigned)(k - 1));
             }
-            env_physics_step<PPL, ACT, FORCE, NC, MC>(p, env, k, lane, r, af, poi, in.apos, out.apos, out.avel);
+            if (p.mode == 0) {
+                env_physics_step<PPL, ACT, FORCE, NC, MC>(p, env, k, lane, r, af, poi, in.apos, out.apos, out.avel);
+            } else if (lane < N) {      // observation producer only (dcc_env_obs_write_probe): the reset state, K times
+                out.apos[lane] = make_double2(r.px, r.py); out.avel[lane] = make_double2(r.vx, r.vy);
+            }
             if (p.st_pos || p.st_vel || p.st_energy || p.st_done) write_step_state<PPL>(p, (size_t)k * p.E + env, lane, N, M, r);
 #pragma unroll
             for (int q = 0; q < PPL; ++q) out.en[q * 64 + lane] = r.en[q];
@@ -1503,7 +1507,8 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
     // 1024 envs 16.4 vs 19.8; 16 x 128 x 1024 9.2 vs 16.0; 9 x 500 x 1024 22.7 vs 27.9; 32 x 1024 x 2048 (no force) 232 vs
     // 233.  DCC_NO_SPLIT=1 / DCC_FORCE_SPLIT=1: tests, A/B.
     const bool split_pays = !(env->PPL >= 16 && p.use_force != 0);
-    if (p.obs != nullptr && env->PPL > 1 && act != 1 && p.mode == 0 && !env->no_split &&
+    // (mode 1 with K >= 2 is the write probe: it must stream through the same kernel shape as the rollouts it stands for)
+    if (p.obs != nullptr && env->PPL > 1 && act != 1 && (p.mode == 0 || p.K >= 2) && !env->no_split &&
         ((p.E <= kSplitMaxEnvs && split_pays) || env->force_split)) {   // single steps too: 24.8 -> 22.2 us at the c4 shard
         kernel_fn fn = pick_split_kernel(env->PPL, act, p.use_force != 0, p.N, p.M, allow_spec);
         hipLaunchKernelGGL(fn, dim3(p.E), dim3(kSplitBlock), env->lds_bytes_split, s, p);
