@@ -1201,7 +1201,10 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
 // stores alternate instead of overlapping.  Here the rows of an env are produced by kSplitObs waves in parallel (each a
 // contiguous, float4-aligned range of agent rows with its own staging window) while the physics wave is already on
 // the next step; the hand-off is the double-buffered LDS slot of the role-specialised kernel, sized for any M.
-constexpr int kSplitObs = 3;
+#ifndef DCC_SPLIT_OBS
+#define DCC_SPLIT_OBS 2     // observation waves per env.  c4 shard, placement-probed buffers, same box: 1 -> 2.27-2.30 ms per 150-step
+#endif                      // launch, 2 -> 2.25-2.27, 3 -> 2.29-2.31, 4 -> 2.79 (a fifth wave per workgroup no longer fits one round)
+constexpr int kSplitObs = DCC_SPLIT_OBS;
 constexpr int kSplitBlock = 64 * (1 + kSplitObs);
 struct SplitSlot { double2* apos; double2* avel; float* en; unsigned* dm; };
 __device__ __forceinline__ int split_slot_bytes(int N, int ppl) { return N * 32 + ppl * 256 + 256; }
@@ -1274,11 +1277,11 @@ __global__ __launch_bounds__(kSplitBlock, (PPL >= 8 || FORCE ? 1 : 2)) void dcc_
     double2* s_poi = reinterpret_cast<double2*>(smem);
     const int sb = split_slot_bytes(N, PPL);
     unsigned char* hbase = smem + ((M * 16 + 15) & ~15);
-    unsigned* flags = reinterpret_cast<unsigned*>(hbase + 2 * sb);
-    float* stg_base = reinterpret_cast<float*>(hbase + 2 * sb + 16);
+    unsigned* flags = reinterpret_cast<unsigned*>(hbase + 2 * sb);                 // ready, consumed[kSplitObs] (<= 8 words)
+    float* stg_base = reinterpret_cast<float*>(hbase + 2 * sb + 32);
 
     for (int j = threadIdx.x; j < M; j += kSplitBlock) s_poi[j] = p.poi[j];
-    if (threadIdx.x < 4) flags[threadIdx.x] = 0u;
+    if (threadIdx.x < 8) flags[threadIdx.x] = 0u;
     __syncthreads();
     PoiLane<PPL> poi;
     poi.init(s_poi, lane, M);
@@ -1716,7 +1719,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     { const char* fs = std::getenv("DCC_FORCE_SPLIT"); e->force_split = fs && fs[0] == '1'; }
     e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kRolesObs * kStageC * 4;
     e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);
-    e->lds_bytes_split = (size_t)((M * 16 + 15) & ~15) + 2 * ((size_t)N * 32 + (size_t)p2 * 256 + 256) + 16 +
+    e->lds_bytes_split = (size_t)((M * 16 + 15) & ~15) + 2 * ((size_t)N * 32 + (size_t)p2 * 256 + 256) + 32 +
                          (size_t)kSplitObs * kStageC * 4;
 
     auto cleanup = [&](int code, const std::string& m) { dcc_env_destroy(e); return fail(code, m); };
