@@ -382,7 +382,7 @@ def main():
     ap.add_argument("--r-comm", type=float, default=0.4)
     ap.add_argument("--actions", choices=["hbm", "rng"], default="hbm",
                     help="hbm: read pre-generated actions [T,E,N,2] (full byte contract); rng: draw in-kernel")
-    ap.add_argument("--place-tries", type=int, default=8,
+    ap.add_argument("--place-tries", type=int, default=12,
                     help="candidate allocations of the observation buffer to time before the run (0 = take the first)")
     ap.add_argument("--no-obs", action="store_true", help="skip the obs write (state-only variant, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
