@@ -1505,8 +1505,9 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
     }
     // several PoIs per lane and few envs (the c4 / c5 shards): one env per workgroup, rows produced by kSplitObs waves
     // while the physics wave runs ahead.  With many envs the fused kernel already fills the chip (c4 x 8192: 0.82 of
-    // peak) and stays the choice, and so it does for 16 PoIs per lane with the pull force on (c5: the single physics wave
-    // of a workgroup becomes the bottleneck: 398 vs 245 us/step).  Measured (us/step split vs fused, same box): 16 x 256 x
+    // peak) and stays the choice, and so it does for 16 PoIs per lane with the pull force on (c5: 398 vs 245 us/step --
+    // the split form is not resident in one round there: its LDS admits 4 of the 8 workgroups a CU needs at 2048 envs, and the
+    // 226 VGPRs of that physics allow one wave per env chip-wide).  Measured (us/step split vs fused, same box): 16 x 256 x
     // 1024 envs 16.4 vs 19.8; 16 x 128 x 1024 9.2 vs 16.0; 9 x 500 x 1024 22.7 vs 27.9; 32 x 1024 x 2048 (no force) 232 vs
     // 233.  DCC_NO_SPLIT=1 / DCC_FORCE_SPLIT=1: tests, A/B.
     const bool split_pays = !(env->PPL >= 16 && p.use_force != 0);
