@@ -1777,10 +1777,10 @@ int dcc_env_reset(dcc_env* e, float* obs, void* stream) {
 }
 
 // K repetitions of the observation producer only (reset state, no physics): the env kernels' own store pattern -- isolates
-// the LDS staging + HBM store pipeline, and is what dcc_env_obs_write_probe times to tell a well-placed output buffer from
-// a badly placed one.
-__attribute__((visibility("default"))) int dcc_debug_obs_only(dcc_env* e, int32_t K, float* obs, void* stream) {
-    if (!e || K < 1) return fail(DCC_EINVAL, "dcc_debug_obs_only: bad argument");
+// the LDS staging + HBM store pipeline, and is what a caller times to tell a well-placed output buffer from a badly placed one.
+int dcc_env_obs_write_probe(dcc_env* e, int32_t K, float* obs, void* stream) {
+    if (!e || K < 1) return fail(DCC_EINVAL, "dcc_env_obs_write_probe: null env or K < 1");
+    if (!obs) return fail(DCC_EINVAL, "dcc_env_obs_write_probe: obs is NULL");
     DeviceGuard guard(e->device);
     KParams p = e->base;
     p.mode = 1; p.K = K;
@@ -1789,11 +1789,6 @@ __attribute__((visibility("default"))) int dcc_debug_obs_only(dcc_env* e, int32_
     o.obs = obs;
     fill_out(p, &o);
     return launch(e, p, 0, stream);
-}
-
-int dcc_env_obs_write_probe(dcc_env* e, int32_t K, float* obs, void* stream) {
-    if (!obs) return fail(DCC_EINVAL, "dcc_env_obs_write_probe: obs is NULL");
-    return dcc_debug_obs_only(e, K, obs, stream);
 }
 
 int dcc_env_step(dcc_env* e, const void* actions, int act_dtype, const dcc_env_out* out, void* stream) {

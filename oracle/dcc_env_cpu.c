@@ -9,6 +9,7 @@
  * (uav_dcc_control/envs/wrappers.py:204-261).
  */
 #include "dcc_oracle.c"
+#include "dcc_gae_cpu.c"   /* the twin of include/dcc_gae.h, same library */
 
 #include "../include/dcc_env.h"
 

@@ -25,7 +25,8 @@ def build(force=False):
     lock: the ranks of a multi-GPU bench import this module at the same time."""
     import fcntl
     src = os.path.join(_HERE, "dcc_env_cpu.c")       # includes dcc_oracle.c: one translation unit
-    deps = [src, os.path.join(_HERE, "dcc_oracle.c"), os.path.join(_HERE, "..", "include", "dcc_env.h")]
+    deps = [src, os.path.join(_HERE, "dcc_oracle.c"), os.path.join(_HERE, "dcc_gae_cpu.c"),
+            os.path.join(_HERE, "..", "include", "dcc_env.h"), os.path.join(_HERE, "..", "include", "dcc_gae.h")]
     def stale():
         return force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(d) for d in deps)
     if stale():
@@ -61,8 +62,25 @@ def lib():
         L.dcc_oracle_rng_actions.restype = None
         L.dcc_oracle_rollout_rng.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
                                              ctypes.c_int, vp, vp, vp, vp]
+        L.dcc_gae_compute_cpu.argtypes = [vp, vp, vp, vp, ctypes.c_double, ctypes.c_double, vp, vp, ctypes.c_int32, ctypes.c_int64, vp]
         _lib = L
     return _lib
+
+
+def gae_compute_cpu(rewards, value_preds, masks, denorm, gamma, gae_lambda, returns, advantages=None):
+    """The `_cpu` twin of include/dcc_gae.h's dcc_gae_compute on contiguous float32 numpy arrays (same argument order and
+    shapes as dcc_hip.gae_compute: rewards [T,C], value_preds / masks / returns [T+1,C], denorm [2] or None, advantages [T,C])."""
+    T, C = rewards.shape
+    for a, shape in ((rewards, (T, C)), (value_preds, (T + 1, C)), (masks, (T + 1, C)), (returns, (T + 1, C))):
+        assert a.dtype == np.float32 and a.flags.c_contiguous and a.shape == shape
+    if advantages is not None:
+        assert advantages.dtype == np.float32 and advantages.flags.c_contiguous and advantages.shape == (T, C)
+    dn = None if denorm is None else np.ascontiguousarray(denorm, np.float32)
+    rc = lib().dcc_gae_compute_cpu(_p(rewards), _p(value_preds), _p(masks), _p(dn), float(gamma), float(gae_lambda),
+                                   _p(returns), _p(advantages), T, C, None)
+    if rc != 0:
+        raise RuntimeError("dcc_gae_compute_cpu failed: %d" % rc)
+    return returns
 
 
 def _p(a):

@@ -39,6 +39,27 @@ def test_library_exports_every_declared_symbol():
     assert lib.dcc_abi_version() == 2
 
 
+def test_library_exports_nothing_the_headers_do_not_declare():
+    """Every dcc_* symbol in the dynamic symbol table of libdcc_hip.so is declared in include/*.h (no debug back doors)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _libpath()], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("dcc_")}
+    assert exported, "no dcc_* exports found"
+    assert exported <= set(_declared()), sorted(exported - set(_declared()))
+
+
+def test_cpu_twins_cover_the_reference_path_entry_points():
+    """oracle/libdcc_oracle.so carries a `_cpu` twin (same signature, host pointers) of the entry points that
+    stand for reference functions: the env life cycle / step / rollout / state of include/dcc_env.h and the GAE scan of
+    include/dcc_gae.h.  (The remaining declarations are device utilities without a reference counterpart -- kernel choice,
+    write probe, feature / row expansion of the compact state -- checked against the oracle's rows instead.)"""
+    from oracle import oracle
+    L = ctypes.CDLL(oracle.build())
+    for n in ("dcc_env_create", "dcc_env_destroy", "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout",
+              "dcc_env_get_state", "dcc_env_set_state", "dcc_last_error", "dcc_gae_compute"):
+        assert n in _declared() and hasattr(L, n + "_cpu"), n
+
+
 def test_binding_lists_match_header():
     import dcc_hip
     assert set(dcc_hip.EXPORTS) <= set(_declared())

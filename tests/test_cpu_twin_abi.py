@@ -80,3 +80,60 @@ def test_one_binding_two_libraries(N, M, cfs, oracle_mod):
     sg, sc = gpu.get_state(), cpu.get_state()
     assert np.array_equal(sg["energy"].cpu().numpy(), sc["energy"]) and np.array_equal(sg["done"].cpu().numpy(), sc["done"])
     gpu.close(); cpu.close()
+
+
+# ---- include/dcc_gae.h: dcc_gae_compute_cpu (oracle/dcc_gae_cpu.c) -------------------------------------------------------------
+
+def _gae_case(T, C, use_vn, seed):
+    rs = np.random.RandomState(seed)
+    rew = rs.normal(-40, 30, (T, C)).astype(np.float32)
+    vp = rs.normal(0, 1, (T + 1, C)).astype(np.float32)
+    mk = (rs.uniform(0, 1, (T + 1, C)) > 0.03).astype(np.float32)
+    dn = np.array([-250.0, 97.5], np.float32) if use_vn else None
+    return rew, vp, mk, dn
+
+
+def test_gae_cpu_twin_reproduces_reference_golden(oracle_mod):
+    """The C twin of dcc_gae_compute on the reference's own buffer (tests/golden/mappo_small.npz: SharedReplayBuffer.compute_returns
+    with ValueNorm, episode ends inside the rollout): returns and raw advantages bit for bit."""
+    from conftest import GOLDEN
+    from oracle import mappo_oracle as mo
+    Z = np.load(os.path.join(GOLDEN, "mappo_small.npz"))
+    T, E, N = 16, 3, 4
+    mean, std = mo.valuenorm_mean_std(Z["vn0_mean"][0], Z["vn0_mean_sq"][0], Z["vn0_debias"])
+    c = lambda a, rows: np.ascontiguousarray(a, np.float32).reshape(rows, E * N)
+    ret = np.zeros((T + 1, E * N), np.float32); adv = np.zeros((T, E * N), np.float32)
+    oracle_mod.gae_compute_cpu(c(Z["buf_rewards"], T), c(Z["buf_value_preds_after"], T + 1), c(Z["buf_masks"], T + 1),
+                               np.array([mean, std], np.float32), 0.99, 0.95, ret, adv)
+    np.testing.assert_array_equal(ret.reshape(T + 1, E, N, 1)[:-1], Z["returns"][:-1])
+    np.testing.assert_array_equal(adv.reshape(T, E, N, 1), Z["adv_raw"])
+    assert not ret[-1].any()                                          # row T untouched, as in the reference
+
+
+@pytest.mark.parametrize("T,C,use_vn", [(150, 513, True), (150, 100, False), (7, 33, True), (1, 1, True), (33, 7, False)])
+def test_gae_cpu_twin_equals_the_numpy_restatement(T, C, use_vn, oracle_mod):
+    from oracle import mappo_oracle as mo
+    rew, vp, mk, dn = _gae_case(T, C, use_vn, T * 7 + C)
+    ref, _ = mo.compute_returns_gae(rew, vp, mk, vp[-1], 0.99, 0.95, *((dn[0], dn[1]) if use_vn else (None, None)))
+    ret = np.zeros((T + 1, C), np.float32); adv = np.zeros((T, C), np.float32)
+    oracle_mod.gae_compute_cpu(rew, vp, mk, dn, 0.99, 0.95, ret, adv)
+    np.testing.assert_array_equal(ret[:-1], ref[:-1])
+    np.testing.assert_array_equal(adv, ref[:-1] - ((vp[:-1] * dn[1] + dn[0]) if use_vn else vp[:-1]))
+    assert oracle_mod.lib().dcc_gae_compute_cpu(None, None, None, None, 0.99, 0.95, None, None, T, C, None) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,C,use_vn", [(150, 4096 * 8, True), (150, 1000, False), (17, 65, True), (400, 129, True)])
+def test_gae_one_binding_two_libraries(T, C, use_vn, oracle_mod):
+    """dcc_gae_compute (device pointers) and dcc_gae_compute_cpu (host pointers), same arguments: identical bits."""
+    import torch
+    import dcc_hip
+    rew, vp, mk, dn = _gae_case(T, C, use_vn, T + C)
+    ret_c = np.zeros((T + 1, C), np.float32); adv_c = np.zeros((T, C), np.float32)
+    oracle_mod.gae_compute_cpu(rew, vp, mk, dn, 0.99, 0.95, ret_c, adv_c)
+    dev = torch.device("cuda")
+    ret_g = torch.zeros(T + 1, C, device=dev); adv_g = torch.zeros(T, C, device=dev)
+    dcc_hip.gae_compute(torch.from_numpy(rew).to(dev), torch.from_numpy(vp).to(dev), torch.from_numpy(mk).to(dev),
+                        torch.from_numpy(dn).to(dev) if use_vn else None, 0.99, 0.95, ret_g, adv_g)
+    np.testing.assert_array_equal(ret_g.cpu().numpy(), ret_c)
+    np.testing.assert_array_equal(adv_g.cpu().numpy(), adv_c)

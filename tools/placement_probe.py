@@ -20,7 +20,7 @@ def run(out, n=24):
     torch.cuda.synchronize()
     return float(np.mean([x.elapsed_time(y) for x, y in ev][4:]))
 import ctypes
-L = env.lib; L.dcc_debug_obs_only.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+L = env.lib; L.dcc_env_obs_write_probe.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
 def timed(f, n=6):
     f(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,7 +31,7 @@ def timed(f, n=6):
 for rnd in range(2):
     print("round %d env rollout ms: " % rnd + "  ".join("%.4f" % run(o) for o in outs), flush=True)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-print("obs-only launch ms     : " + "  ".join("%.4f" % timed(lambda o=o: L.dcc_debug_obs_only(env._h, T, ctypes.c_void_p(o["obs"].data_ptr()), st)) for o in outs))
+print("obs-only launch ms     : " + "  ".join("%.4f" % timed(lambda o=o: L.dcc_env_obs_write_probe(env._h, T, ctypes.c_void_p(o["obs"].data_ptr()), st)) for o in outs))
 print("memset of obs, ms      : " + "  ".join("%.4f" % timed(lambda o=o: o["obs"].zero_()) for o in outs))
 small = [o["obs"][:8] for o in outs]      # the first 8 steps only: 354 MB
 print("memset of 8 steps, ms  : " + "  ".join("%.4f" % timed(lambda o=o: o.zero_(), 20) for o in small))
