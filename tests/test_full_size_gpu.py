@@ -28,6 +28,8 @@ def _pois(M):
 SHAPES = [
     # name,       N,  M,    E,    cfs, r_comm, K,  chunk, kernel the launch resolves to
     ("c4-shard", 16, 256, 1024, 0.0, 0.15, 60, 20),      # split kernel <4,ACT,false,16,256>: 1 physics + 3 observation waves per env
+    ("c4-shard-force", 16, 256, 1024, 0.5, 0.15, 40, 20),   # split kernel <4,ACT,true,16,256>: the pull force (both branches fire at
+                                                           # r_comm 0.15, the env_n16m256_c4 golden's constants) with every CU busy
     ("c5-shard", 32, 1024, 2048, 0.5, 0.10, 50, 10),     # fused generic <16,ACT,true,0,0>: 16 PoIs per lane, pull force on
     ("c5-noforce", 32, 1024, 2048, 0.0, 0.10, 20, 10),   # split generic <16,ACT,false,0,0>
     ("c2", 8, 64, 4096, 0.0, 0.40, 150, 50),             # roles kernel <ACT,false,8,64> with state outputs
