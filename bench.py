@@ -55,59 +55,75 @@ def _host_threads():
     return n
 
 
-def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, budget_s=10.0, E_thr=64, K=25, single_s=2.0, label="c2"):
-    """Time the CPU restatement on a bounded sample of the same workload THROUGH THE SAME C-ABI as the GPU path: the
-    `_cpu` twins of include/dcc_env.h (oracle/dcc_env_cpu.c: dcc_env_rollout_cpu with the product's dcc_env_cfg /
-    dcc_env_out structs, host pointers).  Every host thread steps its own batch of 64 envs in fused rollouts of 25 steps
-    (in-kernel action stream, per-step reward / done / flags / coverage written, observation rows produced and cast to
-    float32 like the GPU writes them) until `budget_s` seconds have passed."""
+def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, E=256, K=150, budget_all_s=8.0, budget_single_s=2.5, label="c2"):
+    """the CPU restatement THROUGH THE SAME C-ABI as the GPU path (the `_cpu` twins of
+    include/dcc_env.h, oracle/dcc_env_cpu.c: dcc_env_rollout_cpu with the product's dcc_env_cfg / dcc_env_out structs, host
+    pointers) on a batch of E = 256 envs x K = 150 steps of this (N, M): once on a single thread, once on all host threads
+    (one contiguous env range per thread).  In-kernel action stream, per-step reward / done / flags / coverage written,
+    observation rows produced and cast to float32 like the GPU writes them.  Both legs are bounded: the all-thread leg repeats
+    whole K-step passes until `budget_all_s` has passed (at least one), the single-thread leg stops after `budget_single_s`
+    even if it has not finished its K steps (large shapes) -- `sample` says what was run."""
     from oracle import oracle
     oracle.build()
     cores = _host_threads()
+    sub = 10                                           # steps per C call: the granularity of the time checks
 
-    def make():
-        e = oracle.CpuTwinEnv(E_thr, N, M, poi, r_cover, r_comm, crs, cfs)
+    def make(n_envs):
+        e = oracle.CpuTwinEnv(n_envs, N, M, poi, r_cover, r_comm, crs, cfs)
         e.reset()
-        return e, e.alloc_out(K, obs=True, assign=True)
+        return e, e.alloc_out(sub, obs=True, assign=True)
 
-    o, out1 = make()
+    # ---- single thread: all E envs, K steps (or as many as fit the budget)
+    o, out1 = make(E)
     t0 = time.perf_counter()
-    n1 = 0
-    while time.perf_counter() - t0 < single_s:
-        o.rollout(K, seed=0, step0=n1, out=out1)
-        n1 += K
-    rate1 = E_thr * n1 * N / (time.perf_counter() - t0)
+    k1 = 0
+    while k1 < K and (k1 == 0 or time.perf_counter() - t0 < budget_single_s):
+        o.rollout(sub, seed=0, step0=k1, env0=0, env_total=E, out=out1)
+        k1 += sub
+    dt1 = time.perf_counter() - t0
+    rate1 = E * k1 * N / dt1
     o.close()
-    envs = [make() for _ in range(cores)]
-    counts = [0] * cores
+    # ---- all threads: thread i owns the contiguous env range [i * E / cores, (i + 1) * E / cores), whole passes of K steps
+    bounds = [E * i // cores for i in range(cores + 1)]
+    envs = [make(bounds[i + 1] - bounds[i]) if bounds[i + 1] > bounds[i] else None for i in range(cores)]
+    passes = [0] * cores
     deadline = [0.0]
 
     def work(i):
+        if envs[i] is None:
+            return
         e, out = envs[i]
-        while time.perf_counter() < deadline[0]:
-            e.rollout(K, seed=1 + i, step0=counts[i], out=out)   # ctypes releases the GIL inside the C call
-            counts[i] += K
+        while passes[i] == 0 or time.perf_counter() < deadline[0]:
+            for k in range(0, K, sub):                # ctypes releases the GIL inside the C call
+                e.rollout(sub, seed=1 + passes[i], step0=k, env0=bounds[i], env_total=E, out=out)
+            passes[i] += 1
 
     ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
     t0 = time.perf_counter()
-    deadline[0] = t0 + budget_s
+    deadline[0] = t0 + budget_all_s
     for t in ths:
         t.start()
     for t in ths:
         t.join()
     dt = time.perf_counter() - t0
-    value = E_thr * sum(counts) * N / dt
+    env_steps = sum((bounds[i + 1] - bounds[i]) * passes[i] * K for i in range(cores))
+    value = env_steps * N / dt
+    for ev in envs:
+        if ev is not None:
+            ev[0].close()
     try:
         model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
     return {"value": value, "unit": "agent-env-steps/s", "cores": cores, "kind": "port",
             "sample": "oracle/dcc_env_cpu.c (the `_cpu` twins of include/dcc_env.h over the C restatement of the reference env, "
-                      "float64): dcc_env_rollout_cpu, %d threads x %d envs, %.0f s of the %s workload (N=%d, M=%d%s; %d env-steps in "
-                      "total) with the same counter-based random actions, observation rows written; single-thread rate %.0f "
-                      "agent-env-steps/s; host CPU: %s" % (cores, E_thr, dt, label, N, M, ", pull force on" if cfs > 0 else "",
-                                                            E_thr * sum(counts), rate1, model),
-            "value_1core": rate1}
+                      "float64): BASELINE.md 4.2 batch E = %d envs x K = %d steps of the %s workload (N=%d, M=%d%s), counter-based "
+                      "random actions, observation rows written.  All %d host threads (one contiguous env range each): %d-%d whole "
+                      "passes per thread in %.1f s = %d env-steps.  Single thread: %d of the %d steps of the %d envs in %.1f s = %.0f "
+                      "agent-env-steps/s.  Host CPU: %s" % (E, K, label, N, M, ", pull force on" if cfs > 0 else "", cores,
+                                                           min(p for p, ev in zip(passes, envs) if ev is not None), max(passes), dt,
+                                                           env_steps, k1, K, E, dt1, rate1, model),
+            "value_1core": rate1, "batch_envs": E, "batch_steps": K, "single_thread_steps_done": k1}
 
 
 def mappo_iterations(args, iters, warm_iters=2):
@@ -223,8 +239,20 @@ def _agree(dist, backend, dev, ok):
     return bool(t.item() > 0.5)
 
 
-def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, launches=12, warm=3, cfs=0.0, r_comm=0.4,
-                  name="c4 (BASELINE configs[3])", cpu=None, place_tries=4):
+def _traffic_file(key, match):
+    """Offline rocprofv3 PMC traffic of a workload (profiles/rNN/traffic_<key>.json, newest round first), or (None, None)."""
+    for rnd in ("r04", "r03", "r02", "r01"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic_%s.json" % key)))
+            if match(tj["workload"]):
+                return tj, "offline rocprofv3 --pmc passes of the same launch (profiles/%s/traffic_%s.json), not measured in this run" % (rnd, key)
+        except Exception:
+            pass
+    return None, None
+
+
+def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, launches=160, warm=3, cfs=0.0, r_comm=0.4,
+                  name="c4 (BASELINE configs[3])", cpu=None, place_tries=4, key="c4"):
     """Bounded env-step leg at another BASELINE shape with the JOB-WIDE env count fixed (strong scaling): BASELINE
     configs[3] is 16 UAV x 256 PoI x 8192 envs over the GPUs of the job, i.e. 8192 / world envs per GPU, no data-path
     collective.  `launches` fused launches of T steps (in-kernel action stream), HIP-event timed; value = job-wide
@@ -278,6 +306,9 @@ def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, la
     ms = [a.elapsed_time(b) for a, b in ev]
     bstep = dcc_hip.bytes_per_step(N, M, with_actions=False, with_obs=True)
     ach = bstep * E * T / (sum(ms) / len(ms) * 1e-3) / 1e9
+    # HBM bytes the counters saw per env-step of this shape (offline passes), scaled to this launch
+    tj, tsrc = _traffic_file(key, lambda w: (w["n_agents"], w["n_pois"]) == (N, M) and w.get("actions") == "rng")
+    traffic = tj["traffic_bytes_per_env_step"] * E * T if tj else None
     env.close()
     del env, out
     torch.cuda.empty_cache()
@@ -295,9 +326,12 @@ def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, la
                            launches, T),
             "value": E_total * N * T * launches / dt, "unit": "agent-env-steps/s", "scaling": "strong", "n_gpus": world,
             "envs_per_gpu": E, "us_per_step": sum(ms) / len(ms) / T * 1e3,
+            "timed_region_s": dt,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "bytes_per_env_step": bstep, "launch_ms_avg": sum(ms) / len(ms), "launches_timed": len(ms),
-                         "output_placement": placement}}
+                         "traffic": traffic, "traffic_source": tsrc,
+                         "frac_physical": (traffic / (sum(ms) / len(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "bytes_per_env_step": bstep, "launch_ms_avg": sum(ms) / len(ms), "launch_ms_min": min(ms),
+                         "launch_ms_max": max(ms), "launches_timed": len(ms), "output_placement": placement}}
 
 
 def _free_port():
@@ -384,6 +418,8 @@ def main():
                     help="hbm: read pre-generated actions [T,E,N,2] (full byte contract); rng: draw in-kernel")
     ap.add_argument("--place-tries", type=int, default=12,
                     help="candidate allocations of the observation buffer to time before the run (0 = take the first)")
+    ap.add_argument("--first-alloc-launches", type=int, default=48,
+                    help="launches timed into the first-allocated buffer for roofline.first_allocation (outside the timed region)")
     ap.add_argument("--no-obs", action="store_true", help="skip the obs write (state-only variant, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm-r-scale", type=float, default=0.95, help="0 disables the connectivity flags (profiling aid)")
@@ -393,6 +429,7 @@ def main():
                     help="env: BASELINE config 2 (headline) + a bounded c3 leg; mappo: config 3 only as the whole line")
     ap.add_argument("--no-c3", action="store_true", help="--mode env: skip the bounded config-3 (MAPPO) leg")
     ap.add_argument("--c3-iters", type=int, default=2, help="--mode env: timed MAPPO iterations of the c3 leg")
+    ap.add_argument("--leg-place-tries", type=int, default=4, help="candidate output allocations timed per bounded leg (c2_strong / c4 / c5)")
     ap.add_argument("--c3-timeout", type=float, default=240.0, help="give up on the c3 leg after this many seconds")
     ap.add_argument("--iters", type=int, default=2, help="--mode mappo: timed training iterations")
     ap.add_argument("--ppo-epoch", type=int, default=15)
@@ -454,6 +491,9 @@ def main():
     kernel_choice = env.kernel_choice()      # roles vs fused, measured by dcc_env_create on this box
     # the observation buffer is the best-placed of up to --place-tries candidate allocations (the same launch streams 6-8 % slower
     # into some allocations than into others of the same process: HipCoverageEnv.alloc_placed_obs, tools/placement_probe.py)
+    # ... and next to it the figure for the FIRST allocation the process gets, which is what a caller that does not probe streams
+    # into (the learner's default): allocated first, timed over --first-alloc-launches launches outside the timed region
+    out_first = env.alloc_out(T, obs=not args.no_obs, assign=not args.no_assign) if (args.place_tries > 0 and not args.no_obs) else None
     out = env.alloc_out(T, obs=not args.no_obs, assign=not args.no_assign, placed=args.place_tries)
     placement = env.placement_info
     env.reset()
@@ -465,14 +505,14 @@ def main():
         acts = np.random.default_rng(1000 + rank).uniform(-1.0, 1.0, (T, E, N, 2)).astype(np.float32)
         actions = torch.from_numpy(acts).to(dev)
 
-    def run(n_steps, events=None):
+    def run(n_steps, events=None, into=None, n_launches=None):
         """n_steps bench steps = n_steps * L fused launches of T env steps, back to back on the current stream."""
         step0 = 0
-        for _ in range(n_steps * L):
+        for _ in range(n_steps * L if n_launches is None else n_launches):
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            env.rollout(T, actions=actions, seed=0, step0=step0, env0=rank * E, env_total=world * E, out=out)
+            env.rollout(T, actions=actions, seed=0, step0=step0, env0=rank * E, env_total=world * E, out=out if into is None else into)
             if events is not None:
                 e1.record()
                 events.append((e0, e1))
@@ -484,6 +524,21 @@ def main():
         torch.cuda.synchronize()
 
     run(args.warmup)
+    first_alloc = None
+    if out_first is not None:
+        if args.no_scalars:
+            out_first = {k: v for k, v in out_first.items() if k in ("obs", "assign")}
+        run(0, into=out_first, n_launches=4)
+        torch.cuda.synchronize()
+        fe = []
+        run(0, events=fe, into=out_first, n_launches=args.first_alloc_launches)
+        torch.cuda.synchronize()
+        fms = [a.elapsed_time(b) for a, b in fe]
+        first_alloc = sum(fms) / len(fms)
+        del out_first
+        torch.cuda.empty_cache()
+        env.reset()
+        run(1)                                   # back in the steady state of the main buffer
     barrier()
     events = []
     t0 = time.perf_counter()
@@ -524,18 +579,10 @@ def main():
     bstep = dcc_hip.bytes_per_step(N, M, with_actions=actions is not None, with_obs=not args.no_obs)
     alg = bstep * E * T
     ach = alg / (avg_ms * 1e-3) / 1e9
-    traffic, traffic_src = None, None  # HBM bytes per launch: OFFLINE rocprofv3 PMC passes of this workload, not this run
-    for rnd in ("r03", "r02", "r01"):
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic_c2.json")))
-            w = tj["workload"]
-            if (w["n_agents"], w["n_pois"], w["envs"], w["steps_per_launch"]) == (N, M, E, T) and \
-                    (w["actions"] == "hbm") == (actions is not None) and not args.no_obs:
-                traffic = tj["traffic_bytes_per_launch"]
-                traffic_src = "offline rocprofv3 --pmc passes of the same launch (profiles/%s/traffic_c2.json), not measured in this run" % rnd
-                break
-        except Exception:
-            pass
+    # HBM bytes per launch: OFFLINE rocprofv3 PMC passes of this workload, not this run
+    tj, traffic_src = _traffic_file("c2", lambda w: (w["n_agents"], w["n_pois"], w["envs"], w["steps_per_launch"]) == (N, M, E, T) and
+                                    (w["actions"] == "hbm") == (actions is not None) and not args.no_obs)
+    traffic = tj["traffic_bytes_per_launch"] if tj else None
     sms = sorted(ms)
     res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -544,6 +591,13 @@ def main():
                                   else "dcc_env_roles_kernel<ACT,FORCE,NC,MC> (a physics + an observation wave per two envs)") + " -- c2: <..,0,false,8,64>",
                        "kernel_choice": kernel_choice,
                        "output_placement": placement,      # untimed preparation, like the inputs: which allocation the rows go to
+                       # `value` / `frac` above: the placement-probed buffer when --place-tries > 0.  The same launch into the
+                       # process's FIRST allocation (what a caller that does not probe gets), timed outside the timed region:
+                       "value_buffer": "placement-probed (best of %d candidates)" % args.place_tries if args.place_tries > 0 else "first allocation",
+                       "first_allocation": ({"launch_ms_avg": first_alloc, "launches_timed": args.first_alloc_launches,
+                                             "achieved": alg / (first_alloc * 1e-3) / 1e9, "frac": alg / (first_alloc * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "value_equivalent": E * N * T / (first_alloc * 1e-3) * world}
+                                            if first_alloc else None),
                        "bytes_per_env_step": bstep, "timing": "HIP events around every timed launch on the launch stream",
                        "launch_ms_avg": avg_ms, "launch_ms_min": sms[0], "launch_ms_median": sms[len(sms) // 2],
                        "launch_ms_max": sms[-1], "launches_timed": len(ms), "frac_of_achievable_6300": ach / 6300.0,
@@ -582,8 +636,30 @@ def main():
 
         threading.Thread(target=watchdog, daemon=True).start()
 
+        # A rank that dies inside a leg makes the launcher SIGTERM the others; rank 0 may then sit in a collective that will never
+        # complete, where a Python-level signal handler does not run.  The wake-up descriptor is written by the C-level handler
+        # whatever the main thread is doing; a helper thread reads it, prints the line with what is there and ends the process.
+        import signal
+        sig_r, sig_w = os.pipe()
+        os.set_blocking(sig_w, False)
+        signal.signal(signal.SIGTERM, lambda *a: None)
+        signal.set_wakeup_fd(sig_w, warn_on_full_buffer=False)
+
+        def on_sigterm():
+            while True:
+                b = os.read(sig_r, 1)
+                if b and b[0] == signal.SIGTERM:
+                    res.setdefault(current[0], {"error": "terminated by the launcher (SIGTERM) during this leg: another rank failed"})
+                    emit()
+                    os._exit(0)
+
+        threading.Thread(target=on_sigterm, daemon=True).start()
+        kill = os.environ.get("DCC_BENCH_KILL", "")        # test hook "<rank>:<leg>": that rank exits at the start of that leg
+
         def leg(key, fn):
             current[0] = key
+            if kill == "%d:%s" % (rank, key):
+                os._exit(17)
             try:
                 res[key] = fn()
             except Exception as e:  # noqa: BLE001
@@ -592,13 +668,15 @@ def main():
 
         if world > 1:   # BASELINE's metric reads "4096 envs; 1/2/4/8 GPU": the fixed-4096 (STRONG) c2 figure next to the weak `value`
             leg("c2_strong", lambda: env_shape_leg(N, M, 4096, world, rank, local_dev, dist, backend, T=T, launches=16, warm=4, cfs=cfs,
-                                                   r_comm=r_comm, name="c2 strong (BASELINE configs[1] with the job-wide env count fixed)"))
-        leg("c4", lambda: env_shape_leg(16, 256, 8192, world, rank, local_dev, dist, backend,
-                                        cpu=None if args.no_cpu_baseline else dict(budget_s=4.0, E_thr=16, K=10, single_s=1.5)))
+                                                   r_comm=r_comm, name="c2 strong (BASELINE configs[1] with the job-wide env count fixed)", key="c2_strong",
+                                                   place_tries=args.leg_place_tries))
+        # >= 0.5 s timed on one GPU: 160 launches x 30 steps at ~117 us per step (c4), 72 x 4 at ~1.9 ms per step (c5)
+        leg("c4", lambda: env_shape_leg(16, 256, 8192, world, rank, local_dev, dist, backend, launches=160, place_tries=args.leg_place_tries,
+                                        cpu=None if args.no_cpu_baseline else dict(budget_all_s=3.0, budget_single_s=1.5)))
         # BASELINE configs[4]: the branchy wavefront path (pull force on), 16384 envs job-wide; 664 KB of rows per env-step
-        leg("c5", lambda: env_shape_leg(32, 1024, 16384, world, rank, local_dev, dist, backend, T=4, launches=8, warm=2, cfs=0.5,
-                                        r_comm=0.1, name="c5 (BASELINE configs[4])",
-                                        cpu=None if args.no_cpu_baseline else dict(budget_s=4.0, E_thr=4, K=5, single_s=1.5)))
+        leg("c5", lambda: env_shape_leg(32, 1024, 16384, world, rank, local_dev, dist, backend, T=4, launches=72, warm=2, cfs=0.5,
+                                        r_comm=0.1, name="c5 (BASELINE configs[4])", key="c5", place_tries=args.leg_place_tries,
+                                        cpu=None if args.no_cpu_baseline else dict(budget_all_s=3.0, budget_single_s=1.5)))
         leg("c3", lambda: mappo_iterations(args, args.c3_iters))
         done.set()
     emit()

@@ -296,8 +296,8 @@ class SharedReplayBuffer(object):
         for t0 in range(0, T + 1, step):
             t1 = min(T + 1, t0 + step)
             self.expand_rows(t0, t1, obs[t0:t1].view((t1 - t0) * E, N, D))
-        if 0 <= self._cur_slot <= T:
-            obs[self._cur_slot].copy_(self.obs_cur)
+        # (no copy of `obs_cur` into its slot: every slot's rows have just been regenerated from the stored state, bit-identical to
+        # what the env wrote -- and `obs_cur` itself is stale whenever the steps since the last reset produced features only)
         self.obs = obs.as_subclass(_RowTensor)
         self.compact = self.structured = self.store_state = False
         self._featurize = None

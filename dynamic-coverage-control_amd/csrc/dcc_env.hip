@@ -25,8 +25,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "dcc_env.h"
 #include "dcc_internal.h"
@@ -1565,6 +1568,14 @@ int fill_out(KParams& p, const dcc_env_out* out) {
 // short rollout (in-kernel action stream, observation rows into a scratch buffer) through each, timed with HIP events on
 // a private stream; the faster one is used from then on (both are bit-identical: tests/test_env_hip_parity.py runs every
 // golden case through both).  The env state is reset afterwards, i.e. left exactly as dcc_env_create leaves it.
+// The choice is a property of (device, shape): measured once per process and shape, reused by later dcc_env_create calls (every
+// test / every learner creates envs of the same few shapes), so that a library user pays the transient scratch allocation once.
+struct TuneKey { int dev, E, N, M; };
+struct TuneVal { bool prefer_fused; float us[2]; };
+std::mutex g_tune_mu;
+std::vector<std::pair<TuneKey, TuneVal>> g_tune_cache;
+constexpr size_t kTuneScratchMax = (size_t)4 << 30;   // larger batches keep the default shape (role-specialised): no multi-GB spike next to torch's allocator
+
 void autotune_kernel_shape(dcc_env* e) {
     const char* at = std::getenv("DCC_AUTOTUNE");
     if ((at && at[0] == '0') || e->PPL != 1 || e->no_roles || e->force_roles) return;
@@ -1573,6 +1584,15 @@ void autotune_kernel_shape(dcc_env* e) {
     // K: the role-specialised shape pays a pipeline fill / drain of about two steps per launch (the observation wave
     // trails the physics wave), which a short measurement would count against it: 64 steps keep that bias at 3 %.
     const int K = 64;
+    if (step_bytes * K > kTuneScratchMax) return;
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        for (const auto& kv : g_tune_cache)
+            if (kv.first.dev == e->device && kv.first.E == e->cfg.n_envs && kv.first.N == e->cfg.n_agents && kv.first.M == e->cfg.n_pois) {
+                e->prefer_fused = kv.second.prefer_fused; e->tune_us[0] = kv.second.us[0]; e->tune_us[1] = kv.second.us[1]; e->tuned = 1;
+                return;
+            }
+    }
     float* scratch = nullptr;
     hipStream_t st = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -1604,10 +1624,15 @@ void autotune_kernel_shape(dcc_env* e) {
         // by more than the measurement's own bias and noise
         e->prefer_fused = best[1] < 0.94f * best[0];
         e->tuned = 1;
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        g_tune_cache.push_back({TuneKey{e->device, e->cfg.n_envs, e->cfg.n_agents, e->cfg.n_pois},
+                                TuneVal{e->prefer_fused, {e->tune_us[0], e->tune_us[1]}}});
     } else {
         (void)hipGetLastError();
     }
-    // back to the reset state
+    // Back to the reset state -- after everything issued on the private stream has finished (on the error path a kernel may still
+    // be running there, and the memsets below go to the null stream, which a non-blocking stream does not synchronise with).
+    if (st) (void)hipStreamSynchronize(st);
     const size_t E = e->cfg.n_envs, N = e->cfg.n_agents, M = e->cfg.n_pois;
     (void)hipMemset(e->d_pos, 0, sizeof(double2) * E * N); (void)hipMemset(e->d_vel, 0, sizeof(double2) * E * N);
     (void)hipMemset(e->d_energy, 0, sizeof(float) * E * M); (void)hipMemset(e->d_done, 0, E * M);

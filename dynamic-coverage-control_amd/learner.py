@@ -117,6 +117,7 @@ class Learner:
         self.eval_interval, self.log_interval = self.cfg.eval_interval, self.cfg.log_interval
         self.is_save_model, self.save_interval = self.cfg.save_model, self.cfg.save_interval
         self.start_iter, self.cur_iter = 1, 0
+        self.resume_partial = False      # a checkpoint of another job shape was loaded: replicated state only (load_checkpoint)
         self.total_env_steps = 0
         if getattr(self.cfg, "load_model", False):
             self.load_model(self.cfg.load_model_path)
@@ -282,7 +283,8 @@ class Learner:
         if self.recurrent:          # learner.py:231-252 with the GRU states and masks of this step, one critic row per agent
             masks = r_buffer.masks[cur_step].reshape(E * N, 1)
             actions, logp, rnn_a = self.policy.actor(obs, r_buffer.rnn_states[cur_step].reshape(E * N, *r_buffer.rnn_states.shape[3:]), masks)
-            values, rnn_c = self.policy.critic(r_buffer.share_obs[cur_step].reshape(E * N, -1),
+            so = r_buffer.share_obs_env_at(cur_step).unsqueeze(1).expand(E, N, -1)     # a view per agent, no [T+1,E,N,S] accessor detour
+            values, rnn_c = self.policy.critic(so.reshape(E * N, -1),
                                                r_buffer.rnn_states_critic[cur_step].reshape(E * N, *r_buffer.rnn_states.shape[3:]), masks)
             return (values.view(E, N, 1), actions.view(E, N, -1).contiguous(), logp.view(E, N, 1),
                     rnn_a.reshape(E, N, *rnn_a.shape[1:]), rnn_c.reshape(E, N, *rnn_c.shape[1:]))
@@ -364,6 +366,10 @@ class Learner:
                  self.total_env_steps * self.n_agents / max(now - self._start_time, 1e-9)))
         for key, value in kwargs.items():
             print("%s" % key + "".join([", %s: %.4f" % (k, v) for k, v in value.items()]))
+        if self.resume_partial:
+            print("note: resumed from a checkpoint of another job shape -- per-rank RNG streams / env states were not restored, "
+                  "this is not a bit-exact continuation (resume_strict: true refuses such a file)")
+            self.resume_partial = False
         self._check_time = now
 
     def save_model(self, save_path):
@@ -414,8 +420,14 @@ class Learner:
             ck["ranks"] = [{k: ck[k] for k in ("rng_torch", "rng_numpy", "rng_cuda", "env_state")}]
             ck["world_size"] = 1
         if strict_world is None:
-            strict_world = bool(getattr(self.cfg, "resume_strict", False))
-        same_world = ck["world_size"] == self.world and ck["ranks"][self.rank]["env_state"]["pos"].shape[0] == self.train_envs.n_envs
+            # default: a run that CONTINUES TRAINING from the file wants the bit-exact continuation and refuses a job of another
+            # shape; evaluation / parameter hand-over (`resume_strict: false`, or n_iters already reached) takes the lenient path
+            strict_world = getattr(self.cfg, "resume_strict", None)
+            if strict_world is None:
+                strict_world = int(ck["iter"]) < int(self.n_iters)
+            strict_world = bool(strict_world)
+        same_world = (ck["world_size"] == self.world and self.rank < len(ck["ranks"]) and
+                      ck["ranks"][self.rank]["env_state"]["pos"].shape[0] == self.train_envs.n_envs)
         if not same_world and strict_world:
             raise ValueError("checkpoint written by %d ranks, this job has %d (the env shards and RNG streams are per rank)"
                              % (ck["world_size"], self.world))
@@ -430,8 +442,9 @@ class Learner:
             if mine["rng_cuda"] is not None and ptu.device.type == "cuda":
                 torch.cuda.set_rng_state(mine["rng_cuda"], ptu.device)
             self.train_envs.env.set_state(**mine["env_state"])
-        elif self.rank == 0:
+        else:
             import warnings
+            self.resume_partial = True        # recorded in the iteration log of every rank
             warnings.warn("checkpoint %s was written by %d rank(s) with %d envs each; this job has %d rank(s) with %d: parameters, "
                           "optimizer moments, ValueNorm and counters are restored, the per-rank RNG streams and env states are not"
                           % (path, ck["world_size"], ck["ranks"][0]["env_state"]["pos"].shape[0], self.world, self.train_envs.n_envs))

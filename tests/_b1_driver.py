@@ -107,7 +107,7 @@ def main(argv):
         missing.append("vec_env.action_space[0] class name Box")
     for callee, shapes in orch["calls"].items():
         role, _, meth = callee.partition(".")
-        if role in roles:
+        if role in roles and "." not in meth:          # "<role>.<method>"; a dotted remainder is a module path (buffer.shared_buffer.X)
             fn = getattr(roles[role], meth, None)
         else:
             mod_name, _, fn_name = callee.rpartition(".")

@@ -116,3 +116,46 @@ def test_two_ranks_under_the_drivers_launcher():
     d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--envs", "1024", "--launches-per-step", "4", "--no-c3"],
              env={"DCC_BENCH_BACKEND": "gloo"}, launcher=launcher)
     assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2048 and "cpu_baseline" not in d and "c3" not in d
+
+
+def _launch_self(n, extra, env_extra=None, timeout=1500):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, "bench.py", "--gpus", str(n)] + extra
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=dict(env, DCC_BENCH_BACKEND="gloo", **(env_extra or {})))
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), (r.returncode, r.stdout[-1000:], r.stderr[-2000:])
+    return r, json.loads(lines[0])
+
+
+def test_world_8_line_before_the_first_scale_run():
+    """The shape of the driver's 8-GPU command, de-risked on the one GPU: eight ranks over the gloo hook (512 envs each for the
+    headline so that they fit side by side), ONE JSON line, the job proved by the `rccl` object, the fixed-job-size legs at
+    4096 / 8, 8192 / 8 and 16384 / 8 envs per rank, and the c3 leg with its gradient all-reduce over eight ranks."""
+    r, d = _launch_self(8, ["--steps", "2", "--warmup", "1", "--envs", "512", "--launches-per-step", "4", "--c3-iters", "1", "--ppo-epoch", "2",
+                            "--leg-place-tries", "1", "--place-tries", "2", "--c3-timeout", "900"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert d["n_gpus"] == 8 and d["config"]["envs_per_gpu"] == 512 and d["config"]["global_envs"] == 4096 and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 * 512 * 8 * 4 * 150 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
+    assert "cpu_baseline" not in d
+    rc = d["rccl"]
+    assert rc["world_size"] == 8 and rc["allreduce_ok"] and rc["allreduce_of_ones"] == 8.0
+    assert sorted(x["rank"] for x in rc["ranks_seen"]) == list(range(8)) and len({x["pid"] for x in rc["ranks_seen"]}) == 8
+    for key, per_rank, nbytes in (("c2_strong", 512, 11851 - 64), ("c4", 1024, 87563 - 128), ("c5", 2048, 676363 - 256)):
+        leg = d[key]
+        assert "error" not in leg, (key, leg)
+        assert leg["scaling"] == "strong" and leg["n_gpus"] == 8 and leg["envs_per_gpu"] == per_rank
+        assert leg["roofline"]["bytes_per_env_step"] == nbytes and leg["value"] > 0
+    assert "pull force on" in d["c5"]["workload"]
+    c3 = d["c3"]
+    assert "error" not in c3, c3
+    assert c3["n_gpus"] == 8 and c3["grad_allreduce"] == "gloo x8" and all(v == v for v in c3["train_info"].values())
+
+
+def test_a_rank_lost_in_a_leg_still_yields_the_headline():
+    """Rank 3 exits at the start of the c4 leg (test hook): the launcher tears the job down, and rank 0 -- possibly stuck in a
+    collective -- still prints the ONE line with the headline, the legs finished before and the interrupted leg marked."""
+    r, d = _launch_self(4, ["--steps", "2", "--warmup", "1", "--envs", "512", "--launches-per-step", "4", "--c3-iters", "1", "--ppo-epoch", "2",
+                            "--leg-place-tries", "1", "--place-tries", "0", "--c3-timeout", "120"], env_extra={"DCC_BENCH_KILL": "3:c4"}, timeout=600)
+    assert d["n_gpus"] == 4 and d["value"] > 0 and d["roofline"]["launches_timed"] == 8 and d["rccl"]["world_size"] == 4
+    assert "error" not in d["c2_strong"]
+    assert "error" in d["c4"] and all("error" in d[k] for k in ("c5", "c3") if k in d)      # nothing after the loss pretends to have run

@@ -168,7 +168,9 @@ def test_checkpoint_resume_is_bit_faithful(tmp_path):
 def test_checkpoint_of_another_job_size_loads_the_replicated_state(tmp_path):
     """Advisor finding (r02): a checkpoint written by a job of another size (rank count / envs per rank) still carries
     everything that does not depend on it.  It loads with a warning -- parameters, Adam moments, ValueNorm, counters -- and
-    the run continues; `resume_strict` keeps the old refusal."""
+    the run continues -- when asked for (`resume_strict: false`) or when the file's iteration count says there is no training
+    left to continue (evaluation / hand-over).  A run that would CONTINUE TRAINING refuses by default (advisor finding r03: a
+    silent partial resume is not the bit-exact continuation a user expects), and `resume_strict: true` always refuses."""
     import utils.pytorch_utils as ptu
     ptu.set_gpu_mode(True, 0)
     from learner import Learner
@@ -179,9 +181,16 @@ def test_checkpoint_of_another_job_size_loads_the_replicated_state(tmp_path):
     a.rollout(a.rl_buffer, a.train_envs); a.rl_update()
     ck = str(tmp_path / "resume.pt")
     a.save_checkpoint(ck)
-    b = Learner(_cfg(n_rollout_threads=8, seed=5, **kw))
+    d = Learner(_cfg(n_rollout_threads=8, seed=5, **kw))          # default: iteration 1 of 3 -> training would continue -> refuse
+    with pytest.raises(ValueError):
+        d.load_checkpoint(ck)
+    e = Learner(_cfg(n_rollout_threads=8, seed=5, **dict(kw, n_iters=1)))   # nothing left to train: the lenient hand-over
+    with pytest.warns(UserWarning, match="per-rank RNG streams and env states are not"):
+        e.load_checkpoint(ck)
+    b = Learner(_cfg(n_rollout_threads=8, seed=5, resume_strict=False, **kw))
     with pytest.warns(UserWarning, match="per-rank RNG streams and env states are not"):
         b.load_checkpoint(ck)
+    assert b.resume_partial
     assert b.start_iter == 2 and b.total_env_steps == a.total_env_steps
     for (ka, va), (kb, vb) in zip(a.policy.actor.state_dict().items(), b.policy.actor.state_dict().items()):
         assert torch.equal(va, vb), ka
