@@ -51,6 +51,7 @@ struct KParams {
     int mode;                   // 0 = step, 1 = reset
     int vec_ok;                 // obs rows may be stored as float4
     int use_connect, use_force;
+    int roles_envs;             // role-specialised kernel: envs per workgroup (2; 1 for small batches: twice the workgroups, half the chain)
     unsigned magicN;            // ceil(2^20 / N): p / N == (p * magicN) >> 20 for p < 4096
     double sq_cover, sq_thr, sq_thr_s, sq_speed;  // radicand bounds of the threshold tests (see kernel)
     double thr2, dmax, contact_force, contact_margin;
@@ -1069,7 +1070,8 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 = physics, 1 = observation
     const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
     const int L = N * (4 + 2 * (N - 1) + 5 * M);
-    const int env_base = xcd_swizzle(blockIdx.x, gridDim.x) * 2;
+    const int epw = p.roles_envs;                                        // envs of this workgroup: 2 (adjacent), or 1
+    const int env_base = xcd_swizzle(blockIdx.x, gridDim.x) * epw;
 
     // LDS: PoI table | hand-off [env 0..1][slot 0..1] | flags ready[2], consumed[2] | staging window
     double2* s_poi = reinterpret_cast<double2*>(smem);
@@ -1096,7 +1098,7 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
         for (int s = 0; s < 2; ++s) {
             const int env = env_base + s;
             init_act(af[s]);
-            if (env < p.E) {
+            if (env < p.E && s < epw) {
                 load_env_state<PPL>(p, env, lane, N, M, r[s]);
                 // the "previous" slot (1) holds the pre-move positions of step 0
                 Handoff h = handoff_at(hbase + (2 * s + 1) * hb, N);
@@ -1108,7 +1110,7 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int env = env_base + s;
-                if (env >= p.E) continue;
+                if (env >= p.E || s >= epw) continue;
                 const int slot = k & 1;
                 Handoff out = handoff_at(hbase + (2 * s + slot) * hb, N);
                 Handoff in = handoff_at(hbase + (2 * s + (slot ^ 1)) * hb, N);
@@ -1127,7 +1129,7 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-            if (env_base + s < p.E) store_env_state<PPL>(p, env_base + s, lane, N, M, r[s]);
+            if (env_base + s < p.E && s < epw) store_env_state<PPL>(p, env_base + s, lane, N, M, r[s]);
     } else {
         // ---------------- observation wave: expand + stream, one env-step at a time ---------------------------
         // It is the wave that feeds HBM: it outranks the physics waves on its SIMD (they have slack).
@@ -1142,7 +1144,7 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int env = env_base + s;
-                if (env >= p.E) continue;
+                if (env >= p.E || s >= epw) continue;
                 if (kRolesObs == 2 && s != role - 1) continue;       // one observation wave per env
                 spin_until_ge(&flags[s], (unsigned)(k + 1));
                 Handoff h = handoff_at(hbase + (2 * s + (k & 1)) * hb, N);
@@ -1164,7 +1166,7 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
                         const int rel = lane < nd ? lane : lane - nd;
                         const unsigned w = (unsigned)__shfl(t2, 4 * (rel < nd ? rel : nd - 1), 64);   // dword `rel` of this row
                         unsigned* row0 = reinterpret_cast<unsigned*>(p.assign + ((size_t)k * p.E + env_base) * M);
-                        const bool last_of_pair = (s == 1) || (env_base + 1 >= p.E);
+                        const bool last_of_pair = (s == 1) || epw == 1 || (env_base + 1 >= p.E);
                         if (s == 0) assign_w0 = w;
                         if (last_of_pair) {
                             const int n_rows = (s == 1) ? 2 : 1;
@@ -1190,7 +1192,7 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
                     // both envs of the workgroup: one output stream of 2 L floats
                     if (s == 0) { st.w0 = 0; st.gout = p.obs + ((size_t)k * p.E + env_base) * (size_t)L; }
                     produce_obs<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane,
-                                                    s * L, (s == 1) || (env_base + 1 >= p.E));
+                                                    s * L, (s == 1) || epw == 1 || (env_base + 1 >= p.E));
                 }
                 publish(&flags[2 + s], (unsigned)(k + 1), lane);
             }
@@ -1391,6 +1393,8 @@ struct dcc_env {
     bool no_spec = false, no_roles = false, force_roles = false, no_split = false, force_split = false;
     // create-time choice between the role-specialised and the fused kernel for obs-writing multi-step launches with one PoI
     // per lane (which of the two streams faster depends on the box: DESIGN.md 4.1); tune_us: measured us per step of each
+    int roles_envs_forced = 0;  // DCC_ROLES_ENVS = 1 / 2 (tests, A/B); 0 = by batch size
+    int roles1_max = 1024;      // batches up to this many envs run one env per role-specialised workgroup (DCC_ROLES1_MAX)
     bool prefer_fused = false;
     int tuned = 0;              // 0: not measured (shape not eligible, disabled, or the measurement failed), 1: measured
     float tune_us[2] = {0.f, 0.f};   // [0] role-specialised, [1] fused
@@ -1501,7 +1505,10 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
     if (p.obs != nullptr && env->PPL == 1 && !env->no_roles && (p.K >= 2 || env->force_roles) &&
         !(env->prefer_fused && !env->force_roles)) {
         kernel_fn fn = pick_roles_kernel(act, p.use_force != 0, p.N, p.M, allow_spec);
-        const int grid = (p.E + 1) / 2;
+        // Small batches are latency-bound: with two envs per workgroup a 512-env launch is 256 workgroups whose physics wave walks
+        // two envs per step; one env per workgroup fills every CU twice over and halves the dependent chain of a step.
+        p.roles_envs = (env->roles_envs_forced > 0) ? env->roles_envs_forced : (p.E <= env->roles1_max ? 1 : 2);
+        const int grid = (p.E + p.roles_envs - 1) / p.roles_envs;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kRolesBlock), env->lds_bytes_roles, s, p);
         HIP_TRY(hipGetLastError());
         return DCC_OK;
@@ -1719,7 +1726,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     KParams& p = e->base;
     std::memset(&p, 0, sizeof(p));
     p.E = E; p.N = N; p.M = M; p.D = e->D; p.L = e->L; p.H = 4 + 2 * (N - 1);
-    p.K = 1; p.mode = 0;
+    p.K = 1; p.mode = 0; p.roles_envs = 2;
     p.use_connect = c->comm_r_scale > 0;
     const double contact_force = 1e+2 * c->comm_force_scale;  // core.py:109 scaled at CW:16
     p.use_force = contact_force > 0;
@@ -1743,6 +1750,8 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     { const char* fr = std::getenv("DCC_FORCE_ROLES"); e->force_roles = fr && fr[0] == '1'; }
     { const char* ns = std::getenv("DCC_NO_SPLIT"); e->no_split = ns && ns[0] == '1'; }
     { const char* fs = std::getenv("DCC_FORCE_SPLIT"); e->force_split = fs && fs[0] == '1'; }
+    { const char* re = std::getenv("DCC_ROLES_ENVS"); if (re && (re[0] == '1' || re[0] == '2')) e->roles_envs_forced = re[0] - '0'; }
+    { const char* rm = std::getenv("DCC_ROLES1_MAX"); if (rm) e->roles1_max = std::atoi(rm); }
     e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kRolesObs * kStageC * 4;
     e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);
     e->lds_bytes_split = (size_t)((M * 16 + 15) & ~15) + 2 * ((size_t)N * 32 + (size_t)p2 * 256 + 256) + 32 +

@@ -27,7 +27,7 @@ def _mk(c, z, E=None):
                                   c["comm_force_scale"])
 
 
-@pytest.mark.parametrize("variant", ["spec-roles", "spec-fused", "generic-roles", "generic-fused"])
+@pytest.mark.parametrize("variant", ["spec-roles", "spec-roles1", "spec-fused", "generic-roles", "generic-roles1", "generic-fused"])
 @pytest.mark.parametrize("path", golden_env_files(), ids=lambda p: os.path.basename(p)[4:-4])
 def test_hip_step_matches_reference_golden(path, variant, monkeypatch):
     """Every kernel family must reproduce the reference: compile-time (N, M) specialisations vs the generic
@@ -39,8 +39,13 @@ def test_hip_step_matches_reference_golden(path, variant, monkeypatch):
     has_spec = (c["N"], c["M"]) in ((8, 64), (4, 16), (4, 20), (16, 256))
     if spec == "generic" and not has_spec:
         pytest.skip("no specialised kernel for this size: the generic path is what 'spec' already ran")
-    if roles == "roles" and c["M"] > 64 and not c["act_f32"]:
+    if roles.startswith("roles") and c["M"] > 64 and not c["act_f32"]:
         pytest.skip("the split kernel takes float32 / in-kernel actions; float64 actions use the fused kernel")
+    if roles == "roles1" and c["M"] > 64:
+        pytest.skip("one env per workgroup is a shape of the role-specialised kernel (<= 64 PoIs); the split kernel always is")
+    # the role-specialised kernel serves two adjacent envs per workgroup (large batches) or one (small, latency-bound batches)
+    monkeypatch.setenv("DCC_ROLES_ENVS", "1" if roles == "roles1" else "2")
+    roles = "roles" if roles == "roles1" else roles
     monkeypatch.setenv("DCC_NO_SPEC", "1" if spec == "generic" else "0")
     monkeypatch.setenv("DCC_NO_ROLES", "1" if roles == "fused" else "0")
     monkeypatch.setenv("DCC_FORCE_ROLES", "1" if roles == "roles" else "0")   # single-step launches default to fused
@@ -91,12 +96,15 @@ def test_hip_step_matches_reference_golden(path, variant, monkeypatch):
                                             (32, 1024, 0.5, 0.1), (3, 130, 1.0, 0.3), (64, 70, 0.5, 0.08),
                                             (64, 1024, 0.5, 0.05), (1, 1, 0.0, 0.4), (2, 64, 1.0, 0.3), (9, 500, 0.0, 0.2),
                                             (1, 100, 0.0, 0.4), (2, 200, 1.0, 0.5), (7, 65, 0.5, 0.3)])
-@pytest.mark.parametrize("multi_wave", [False, True])
+@pytest.mark.parametrize("multi_wave", [False, True, 2])
 def test_hip_step_matches_oracle_random(N, M, cfs, r_comm, multi_wave, oracle_mod, monkeypatch):
     """Seeded random actions, E=33 envs (not a multiple of the 4 envs per workgroup), 40 steps; with the fused kernel
     and with the multi-wave kernel of the size (roles for M <= 64, split for M > 64) forced for the single-step launches."""
+    if multi_wave == 2 and M > 64:
+        pytest.skip("two envs per workgroup is a shape of the role-specialised kernel (<= 64 PoIs)")
     monkeypatch.setenv("DCC_FORCE_ROLES", "1" if multi_wave else "0")
     monkeypatch.setenv("DCC_FORCE_SPLIT", "1" if multi_wave else "0")
+    monkeypatch.setenv("DCC_ROLES_ENVS", "2" if multi_wave == 2 else "0")     # 0: by batch size (33 envs -> one env per workgroup)
     E, T = (33, 40) if N * M < 20000 else (5, 12)
     rs = np.random.RandomState(N * 1000 + M)
     poi = rs.uniform(-1, 1, (M, 2))
