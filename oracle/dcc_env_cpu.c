@@ -172,3 +172,43 @@ DCC_API int dcc_env_set_state_cpu(dcc_env *env, const double *pos, const double 
     if (done) memcpy(o->done, done, E * M);
     return DCC_OK;
 }
+
+/* The twin of dcc_obs_expand: Scenario.observation (SC:99-110) of every agent for n independent states given as arrays (pos / vel [n,N,2]
+ * f64, energy [n,M] f32, done [n,M] u8) -> obs [n,N,D] float32 (the cast SharedReplayBuffer applies, shared_buffer.py:40).  Same feature order
+ * as observe() in dcc_oracle.c: vel_i, pos_i, (pos_a - pos_i) for a != i, then per PoI (poi_j - pos_i, energy_j, m_energy, done_j).  Uses the
+ * PoI table and constants of `env`; does not touch its state. */
+DCC_API int dcc_obs_expand_cpu(dcc_env *env, int64_t n, const double *pos, const double *vel, const float *energy, const uint8_t *done,
+                               float *obs, void *stream)
+{
+    (void)stream;
+    dcc_env_cpu *c = (dcc_env_cpu *)env;
+    if (!c) return cpu_fail(DCC_EINVAL, "dcc_obs_expand_cpu: null env");
+    if (n < 1 || !pos || !vel || !energy || !done || !obs) return cpu_fail(DCC_EINVAL, "dcc_obs_expand_cpu: bad argument");
+    const dcc_oracle *o = c->o;
+    const int N = o->N, M = o->M, D = o->D;
+    for (int64_t s = 0; s < n; s++) {
+        const double *p = pos + (size_t)s * N * 2, *v = vel + (size_t)s * N * 2;
+        const float *en = energy + (size_t)s * M;
+        const uint8_t *dn = done + (size_t)s * M;
+        for (int i = 0; i < N; i++) {
+            float *out = obs + ((size_t)s * N + i) * D;
+            int k = 0;
+            out[k++] = (float)v[2 * i]; out[k++] = (float)v[2 * i + 1];
+            out[k++] = (float)p[2 * i]; out[k++] = (float)p[2 * i + 1];
+            for (int a = 0; a < N; a++) {
+                if (a == i) continue;
+                out[k++] = (float)(p[2 * a] - p[2 * i]);
+                out[k++] = (float)(p[2 * a + 1] - p[2 * i + 1]);
+            }
+            for (int j = 0; j < M; j++) {
+                out[k++] = (float)(o->poi[2 * j] - p[2 * i]);
+                out[k++] = (float)(o->poi[2 * j + 1] - p[2 * i + 1]);
+                out[k++] = (float)(double)en[j];
+                out[k++] = (float)o->m_energy;
+                out[k++] = dn[j] ? 1.0f : 0.0f;
+            }
+        }
+    }
+    return DCC_OK;
+}
+

@@ -175,6 +175,7 @@ class CpuTwinEnv:
                                           ctypes.POINTER(dcc_hip.EnvOut), vp]
         L.dcc_env_get_state_cpu.argtypes = [vp] * 6
         L.dcc_env_set_state_cpu.argtypes = [vp] * 6
+        L.dcc_obs_expand_cpu.argtypes = [vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp]
         L.dcc_last_error_cpu.restype = ctypes.c_char_p
         self.L = L
         cfg = dcc_hip.EnvCfg()
@@ -243,6 +244,17 @@ class CpuTwinEnv:
         if rc != 0:
             raise RuntimeError(self.L.dcc_last_error_cpu().decode())
         return out
+
+    def expand_obs(self, pos, vel, energy, done):
+        """dcc_obs_expand_cpu: observation rows [n,N,D] float32 of n states (pos / vel [n,N,2] f64, energy [n,M] f32, done [n,M] u8)."""
+        c = lambda a, t: np.ascontiguousarray(a, t)
+        pos, vel, energy, done = c(pos, np.float64), c(vel, np.float64), c(energy, np.float32), c(done, np.uint8)
+        n = pos.shape[0]
+        obs = np.empty((n, self.N, self.D), np.float32)
+        rc = self.L.dcc_obs_expand_cpu(self._h, n, _p(pos), _p(vel), _p(energy), _p(done), _p(obs), None)
+        if rc != 0:
+            raise RuntimeError("dcc_obs_expand_cpu failed: %d" % rc)
+        return obs
 
     def get_state(self):
         st = dict(pos=np.empty((self.E, self.N, 2)), vel=np.empty((self.E, self.N, 2)), energy=np.empty((self.E, self.M), np.float32),

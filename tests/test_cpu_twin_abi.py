@@ -82,6 +82,46 @@ def test_one_binding_two_libraries(N, M, cfs, oracle_mod):
     gpu.close(); cpu.close()
 
 
+@pytest.mark.parametrize("path", [p for p in golden_env_files() if any(t in p for t in ("n8m64", "n4m20", "n5m37", "c4"))] or golden_env_files()[:3],
+                         ids=lambda p: os.path.basename(p)[4:-4])
+def test_obs_expand_cpu_twin_rebuilds_the_reference_rows(path, oracle_mod):
+    """dcc_obs_expand_cpu (Scenario.observation from a state given as arrays, coverage.py:99-110): the rows the reference returned at the
+    golden's sampled steps are rebuilt bit for bit from the state the twin emitted for those steps."""
+    z, c = load_case(path)
+    env = oracle_mod.CpuTwinEnv(c["E"], c["N"], c["M"], z["poi"], c["r_cover"], c["r_comm"], c["comm_r_scale"], c["comm_force_scale"])
+    env.reset()
+    out = env.alloc_out(state=True)
+    obs_steps = list(z["obs_steps"])
+    checked = 0
+    for t in range(c["T"]):
+        a = z["actions"][t]
+        env.step(a.astype(np.float32) if c["act_f32"] else a.astype(np.float64), out)
+        if t in obs_steps:
+            rows = env.expand_obs(out["state_pos"], out["state_vel"], out["state_energy"], out["state_done"])
+            assert np.array_equal(rows, z["obs"][obs_steps.index(t)].astype(np.float32)) and np.array_equal(rows, out["obs"])
+            checked += 1
+    assert checked == len(obs_steps) and checked > 0
+    env.close()
+
+
+@pytest.mark.gpu
+def test_obs_expand_one_binding_two_libraries(oracle_mod):
+    """dcc_obs_expand (device) and dcc_obs_expand_cpu (host) on the same random states: identical rows."""
+    import torch
+    import dcc_hip
+    N, M, n = 8, 64, 300
+    rs = np.random.RandomState(3)
+    poi = rs.uniform(-1, 1, (M, 2))
+    pos, vel = rs.uniform(-1.4, 1.4, (n, N, 2)), rs.uniform(-0.5, 0.5, (n, N, 2))
+    en = rs.randint(0, 9, (n, M)).astype(np.float32); dn = (en >= 5).astype(np.uint8)
+    cpu = oracle_mod.CpuTwinEnv(4, N, M, poi)
+    gpu = dcc_hip.HipCoverageEnv(4, N, M, poi)
+    t = lambda a: torch.from_numpy(a).to(gpu.device)
+    rows_g = gpu.expand_obs(t(pos), t(vel), t(en), t(dn)).cpu().numpy()
+    assert np.array_equal(rows_g, cpu.expand_obs(pos, vel, en, dn))
+    gpu.close(); cpu.close()
+
+
 # ---- include/dcc_gae.h: dcc_gae_compute_cpu (oracle/dcc_gae_cpu.c) -------------------------------------------------------------
 
 def _gae_case(T, C, use_vn, seed):

@@ -33,6 +33,7 @@ SHAPES = [
     ("c5-shard", 32, 1024, 2048, 0.5, 0.10, 50, 10),     # fused generic <16,ACT,true,0,0>: 16 PoIs per lane, pull force on
     ("c5-noforce", 32, 1024, 2048, 0.0, 0.10, 20, 10),   # split generic <16,ACT,false,0,0>
     ("c2", 8, 64, 4096, 0.0, 0.40, 150, 50),             # roles kernel <ACT,false,8,64> with state outputs
+    ("c2-strong-shard", 8, 64, 512, 0.0, 0.40, 150, 50),  # what c2_strong runs per GPU at 8 GPUs: the same kernel with ONE env per workgroup
 ]
 
 
