@@ -64,7 +64,7 @@ constexpr int SLOT = 2 * OPB;            // dZ image | H image
 
 // steps [s0, s1) of 16 rows each for this workgroup; partial [gridDim.x][256 n][256 k]
 __global__ __launch_bounds__(512, 1) void wgrad_x6(const float* __restrict__ dZ, const float* __restrict__ Hm, float* __restrict__ partial,
-                                                    long long M, int steps_total) {
+                                                    long long M, int steps_total, long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // [2][SLOT]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -79,11 +79,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_x6(const float* __restrict__ dZ,
     const int wn = w >> 1, wk = w & 1;
     const int j = lane & 31, g = lane >> 5;
 
-    float2 r0[8], r1[8], r2[8];                              // register ring: step s lives in slot s % 3
-    // (the kernel walks whole 16-row steps only -- `steps_total` = M / 16 -- so no load is conditional: a load under a runtime
-    // condition makes hipcc branch around it and drain vmcnt(0); the <= 15 rows left over are added by wgrad_tail)
+    float2 r0[8], r1[8];                                     // register ring: step s lives in slot s & 1
     auto load = [&](int s, float2 (&r)[8]) __attribute__((always_inline)) {
-        const long long m0 = (long long)(s0 + ((VAR & 1) ? (s % 3) : s)) * 16 + 8 * kg;
+        const long long m0 = (long long)(s0 + ((VAR & 1) ? (s & 3) : s)) * 16 + 8 * kg;
 #pragma unroll
         for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const float2*>(src + (m0 + e) * H + c0);
     };
@@ -136,43 +134,36 @@ __global__ __launch_bounds__(512, 1) void wgrad_x6(const float* __restrict__ dZ,
     // per step): if all of them stage and then all of them multiply, the matrix pipes idle while everybody stages.
     // Waves w and w + 4 share a SIMD.  One of them multiplies first and stages afterwards, the other the other way round, so that on
     // every SIMD one wave keeps the matrix pipe busy while the other one occupies the VALU.
-    auto iter_fast = [&](int s, const float2 (&use)[8], float2 (&fill)[8], const bool mma_first) __attribute__((always_inline)) {
-        load(s + 3, fill);
-        if (mma_first) { mma(s); stage(s + 1, use); }
-        else { stage(s + 1, use); mma(s); }
+    // iteration s: multiply step s, stage step s+1 (slot (s+1) & 1, requested two iterations ago) and re-use its registers for step s+3
+    auto iter_fast = [&](int s, float2 (&slot)[8], const bool mma_first) __attribute__((always_inline)) {
+        const bool rec = dbg && blockIdx.x == 3 && (w == 0 || w == 4) && lane == 0 && s >= 64 && s < 80;
+        long long t0 = 0, t1 = 0, t2 = 0;
+        if (rec) t0 = clock64();
+        if (mma_first) { mma(s); if (rec) t1 = clock64(); stage(s + 1, slot); load(s + 3, slot); }
+        else { stage(s + 1, slot); load(s + 3, slot); if (rec) t1 = clock64(); mma(s); }
+        if (rec) t2 = clock64();
         __syncthreads();
+        if (rec) { long long* d = dbg + ((w >> 2) * 16 + (s - 64)) * 4; d[0] = t0; d[1] = t1; d[2] = t2; d[3] = clock64(); }
     };
-    auto iter = [&](int s, const float2 (&use)[8], float2 (&fill)[8]) __attribute__((always_inline)) {
+    auto iter = [&](int s, float2 (&slot)[8]) __attribute__((always_inline)) {
         if (s >= S) return;
-        if (s + 3 < S) load(s + 3, fill);
-        if (s + 1 < S) stage(s + 1, use);
+        if (s + 1 < S) stage(s + 1, slot);
+        if (s + 3 < S) load(s + 3, slot);
         mma(s);
         __syncthreads();
     };
     if (S > 0) load(0, r0);
-    if (S > 1) load(1, r1);
-    if (S > 2) load(2, r2);
     if (S > 0) stage(0, r0);
+    if (S > 1) load(1, r1);
+    if (S > 2) load(2, r0);
     __syncthreads();
     int s = 0;
     if (w < 4) {
-        for (; s + 5 < S; s += 3) {
-            iter_fast(s, r1, r0, true);      // stages step s+1 (slot 1), refills slot 0 with step s+3
-            iter_fast(s + 1, r2, r1, true);
-            iter_fast(s + 2, r0, r2, true);
-        }
+        for (; s + 5 < S; s += 2) { iter_fast(s, r1, true); iter_fast(s + 1, r0, true); }
     } else {
-        for (; s + 5 < S; s += 3) {
-            iter_fast(s, r1, r0, false);
-            iter_fast(s + 1, r2, r1, false);
-            iter_fast(s + 2, r0, r2, false);
-        }
+        for (; s + 5 < S; s += 2) { iter_fast(s, r1, false); iter_fast(s + 1, r0, false); }
     }
-    for (; s < S; s += 3) {
-        iter(s, r1, r0);
-        iter(s + 1, r2, r1);
-        iter(s + 2, r0, r2);
-    }
+    for (; s < S; s += 2) { iter(s, r1); iter(s + 1, r0); }
     // D[i = n][j = k]: lane (j, g) holds column k = j of rows n = (v & 3) + 8 (v >> 2) + 4 g
     float* P = partial + (size_t)blockIdx.x * H * H;
 #pragma unroll
@@ -218,7 +209,8 @@ int main(int argc, char** argv) {
     }
     const int steps = (int)(M / 16);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x6), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLOT));
-    auto run = [&] { wgrad_x6<<<grid, 512, 2 * SLOT>>>(dZ, Hm, P, M, steps); wgrad_reduce<<<H * H / 256, 256>>>(P, dW, grid, 0);
+    long long* dbg = nullptr; if (argc > 3) { CK(hipMalloc(&dbg, 2 * 16 * 4 * 8)); CK(hipMemset(dbg, 0, 2 * 16 * 4 * 8)); }
+    auto run = [&] { wgrad_x6<<<grid, 512, 2 * SLOT>>>(dZ, Hm, P, M, steps, dbg); wgrad_reduce<<<H * H / 256, 256>>>(P, dW, grid, 0);
                       if (M % 16) wgrad_tail<<<H * H / 256, 256>>>(dZ, Hm, dW, (long long)steps * 16, M); };
     run(); CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -244,6 +236,14 @@ int main(int argc, char** argv) {
             const double e32 = std::fabs((double)f - ref) / sabs;
             worst = e > worst ? e : worst; worst32 = e32 > worst32 ? e32 : worst32; sum += e; ++cnt;
         }
+    if (dbg) {
+        long long h[2 * 16 * 4]; CK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+        for (int r = 0; r < 2; ++r) {
+            printf("wave %d (%s first), steps 64..79: [first phase | second phase | barrier wait] cycles\n ", 4 * r, r ? "stage" : "mma");
+            for (int i = 0; i < 16; ++i) printf(" [%lld|%lld|%lld]", h[(r * 16 + i) * 4 + 1] - h[(r * 16 + i) * 4], h[(r * 16 + i) * 4 + 2] - h[(r * 16 + i) * 4 + 1], h[(r * 16 + i) * 4 + 3] - h[(r * 16 + i) * 4 + 2]);
+            printf("\n");
+        }
+    }
     printf("rows %lld grid %d VAR=%d: %.3f ms  %.1f TF/s fp32-equivalent (%.0f TF/s of bf16 MFMA work, %.0f GB/s of operand reads)\n", M, grid, VAR, ms,
            2.0 * M * H * H / ms / 1e9, 12.0 * M * H * H / ms / 1e9, 2.0 * M * H * 4 / ms / 1e6);
     printf("error / sum|dz.h| vs float64 over %d entries: bf16x6 max %.3e mean %.3e   |   a 4096-row fp32 FMA chain: max %.3e\n", cnt, worst, sum / cnt, worst32);
