@@ -139,8 +139,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_x6(const float* __restrict__ dZ,
         const bool rec = dbg && blockIdx.x == 3 && (w == 0 || w == 4) && lane == 0 && s >= 64 && s < 80;
         long long t0 = 0, t1 = 0, t2 = 0;
         if (rec) t0 = clock64();
-        if (mma_first) { mma(s); if (rec) t1 = clock64(); stage(s + 1, slot); load(s + 3, slot); }
-        else { stage(s + 1, slot); load(s + 3, slot); if (rec) t1 = clock64(); mma(s); }
+#ifndef STAGE_PRIO
+#define STAGE_PRIO 3        // the staging phase outranks the other wave's MFMA stream on the SIMD (it is the one with many short instructions)
+#endif
+        if (mma_first) { mma(s); if (rec) t1 = clock64(); __builtin_amdgcn_s_setprio(STAGE_PRIO); stage(s + 1, slot); load(s + 3, slot); __builtin_amdgcn_s_setprio(0); }
+        else { __builtin_amdgcn_s_setprio(STAGE_PRIO); stage(s + 1, slot); load(s + 3, slot); __builtin_amdgcn_s_setprio(0); if (rec) t1 = clock64(); mma(s); }
         if (rec) t2 = clock64();
         __syncthreads();
         if (rec) { long long* d = dbg + ((w >> 2) * 16 + (s - 64)) * 4; d[0] = t0; d[1] = t1; d[2] = t2; d[3] = clock64(); }
