@@ -306,10 +306,17 @@ __global__ __launch_bounds__(512, 1) void gemm_x6_pc(const float* __restrict__ X
 #else
         auto step = [&](int g, const float4 (&use)[4], float4 (&fill)[4]) {
             if (g + 1 < G) x_split_store(g + 1, use);
+            if (VAR & 32) {     // timing experiment: the tile's 128 KB of output leave from the PRODUCERS, 16 KB per iteration, 1 KB-contiguous stores
+                const long long row = ((long long)blockIdx.x + (long long)(g >> 3) * gridDim.x) * BM + 16 * (g & 7) + 4 * pw;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (row + q < M) *reinterpret_cast<float4*>(Y + (row + q) * ldy + 4 * lane) = use[q];
+            }
             if (g + 1 < G && (!(VAR & 4) || g < 8)) w_copy(g + 1);
             if (g + 3 < G) {
                 x_load(g + 3, fill);
-                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (VAR & 32) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
