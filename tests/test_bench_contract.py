@@ -54,8 +54,18 @@ def test_the_drivers_exact_command_is_a_real_measurement():
     d = _run(["--gpus", "1", "--steps", "20", "--warmup", "5"])
     _check_line(d, 20, 5)
     assert d["ms_per_step"] * d["steps"] >= 500.0 and d["config"]["timed_region_s"] >= 0.5
+    # the figure for the process's FIRST allocation (what a caller that does not probe placements gets) rides in the same line
+    fa = d["roofline"]["first_allocation"]
+    assert d["roofline"]["value_buffer"].startswith("placement-probed") and fa["launches_timed"] == 48 and 0.3 < fa["frac"] < 1.0
+    assert abs(fa["frac"] - d["roofline"]["algorithmic_bytes_per_launch"] / (fa["launch_ms_avg"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+    assert fa["frac"] <= d["roofline"]["frac"] * 1.03          # the probed buffer is never meaningfully worse than the first one
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e5 and "sample" in c
+    assert c["batch_envs"] == 256 and c["batch_steps"] == 150 and c["single_thread_steps_done"] == 150      # BASELINE.md 4.2 batch
+    for leg in ("c4", "c5"):                               # bounded legs are measurements: >= 0.5 s timed, physical fraction beside the algorithmic one
+        assert d[leg]["timed_region_s"] >= 0.5, (leg, d[leg]["timed_region_s"])
+        rl = d[leg]["roofline"]
+        assert rl["traffic"] is None or (rl["frac_physical"] < rl["frac"] and "offline" in rl["traffic_source"])
     assert d["value"] > 50e6                          # the north-star floor, by a wide margin
     assert "rccl" not in d and "c2_strong" not in d          # single process: no process group, strong == weak
     c4 = d["c4"]
