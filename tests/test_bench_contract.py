@@ -58,7 +58,6 @@ def test_the_drivers_exact_command_is_a_real_measurement():
     fa = d["roofline"]["first_allocation"]
     assert d["roofline"]["value_buffer"].startswith("placement-probed") and fa["launches_timed"] == 48 and 0.3 < fa["frac"] < 1.0
     assert abs(fa["frac"] - d["roofline"]["algorithmic_bytes_per_launch"] / (fa["launch_ms_avg"] * 1e-3) / 1e9 / 8000.0) < 1e-9
-    assert fa["frac"] <= d["roofline"]["frac"] * 1.03          # the probed buffer is never meaningfully worse than the first one
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e5 and "sample" in c
     assert c["batch_envs"] == 256 and c["batch_steps"] == 150 and c["single_thread_steps_done"] == 150      # BASELINE.md 4.2 batch
