@@ -156,10 +156,6 @@ def mappo_iterations(args, iters, warm_iters=2):
         torch.cuda.synchronize()
         return t1 - t0, time.perf_counter() - t1, info, tinfo
 
-    if world > 1 and os.environ.get("DCC_BENCH_BACKEND") == "gloo" and world > torch.cuda.device_count():
-        # test hook only (several ranks time-slicing ONE device): eight processes bringing up the same code objects on one GPU at the same
-        # moment occasionally fault inside a stock torch kernel (profiles/r04/world8_on_one_gpu.txt); let them take their first step one by one
-        time.sleep(0.4 * int(os.environ.get("RANK", "0")))
     for _ in range(warm_iters):  # hipBLASLt heuristics, allocator, eager rollout + hipGraph capture, first replay
         one_iter()
     dist = None
