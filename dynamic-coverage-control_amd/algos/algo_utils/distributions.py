@@ -19,14 +19,33 @@ class AddBias(nn.Module):
         return x + self._bias.t().view(1, -1)
 
 
+_noise_source = None
+
+
+def set_noise_source(fn):
+    """Replace the standard-normal draws of action sampling: fn(shape, dtype, device) -> tensor, None restores torch.randn.
+    The reference draws from torch's global generator (torch.distributions.Normal.sample, act.py:79-84); this seam lets a
+    recorded noise sequence of a reference run be replayed through this package's rollout (tests/test_learner_reference_replay.py).
+    Returns the previous source."""
+    global _noise_source
+    prev, _noise_source = _noise_source, fn
+    return prev
+
+
+def standard_normal(shape, dtype, device):
+    """eps ~ N(0, 1) of action sampling (a = mean + std * eps), from the active noise source."""
+    if _noise_source is not None:
+        return _noise_source(tuple(shape), dtype, device)
+    return torch.randn(shape, dtype=dtype, device=device)
+
+
 class FixedNormal(torch.distributions.Normal):
     def sample(self, sample_shape=torch.Size()):
         """mean + std * eps.  torch.normal(mean, std) -- what Normal.sample calls -- checks `std.min() >= 0` on the
         host: a device synchronisation per rollout step and illegal inside a hipGraph capture."""
         shape = self._extended_shape(sample_shape)
         with torch.no_grad():
-            return self.loc.expand(shape) + self.scale.expand(shape) * torch.randn(shape, dtype=self.loc.dtype,
-                                                                                     device=self.loc.device)
+            return self.loc.expand(shape) + self.scale.expand(shape) * standard_normal(shape, self.loc.dtype, self.loc.device)
 
     def log_probs(self, actions):
         return super().log_prob(actions).sum(-1, keepdim=True)

@@ -171,7 +171,10 @@ class MAPPOTrainer:
         """Forward pass + the three loss terms of mappo.py:139-164 on one batch (or one chunk of it)."""
         (share_obs_batch, obs_batch, rnn_states_batch, rnn_states_critic_batch, actions_batch, value_preds_batch,
          return_batch, masks_batch, active_masks_batch, old_action_log_probs_batch, adv_targ,
-         available_actions_batch) = sample
+         available_actions_batch) = sample[:12]
+        # row mini-batches whose inputs are held per (step, env) pair (SharedReplayBuffer.minibatch_rows): which actor output /
+        # which critic output belongs to each row of the mini-batch
+        row_sel, pair_sel = sample[12] if len(sample) > 12 else (None, None)
         t = lambda x: ptu.to_tensor(x) if x is not None else None
         old_logp, adv_targ = t(old_action_log_probs_batch), t(adv_targ)
         value_preds_batch, return_batch, active_masks_batch = t(value_preds_batch), t(return_batch), t(active_masks_batch)
@@ -186,13 +189,16 @@ class MAPPOTrainer:
         actor = self.policy.actor
         on_gpu = ptu.device.type == "cuda"
         fused_loss = on_gpu and available_actions_batch is None and fused.policy_loss_usable(actions_batch, old_logp)
-        if fused_loss:      # surrogate, entropy and their gradients in one HIP pass over [B, A] (dcc_ppo_policy_loss)
-            mean = actor._mean(obs_batch, prenormalized, rnn_states_batch, masks_batch)
-        else:
-            action_log_probs, dist_entropy = actor.evaluate_actions(
-                obs_batch, rnn_states_batch, actions_batch, masks_batch, available_actions_batch, active_masks_batch,
-                prenormalized=prenormalized)
+        mean = actor._mean(obs_batch, prenormalized, rnn_states_batch, masks_batch)
+        if row_sel is not None:
+            mean = mean.index_select(0, row_sel)
+        if not fused_loss:  # (fused: surrogate, entropy and their gradients in one HIP pass over [B, A], dcc_ppo_policy_loss)
+            action_log_probs, dist_entropy = actor.act.evaluate_actions(
+                None, actions_batch, available_actions_batch,
+                active_masks=active_masks_batch if actor._use_policy_active_masks else None, mean=mean)
         values = self.policy.critic(share_obs_batch, rnn_states_critic_batch, masks_batch, prenormalized=prenormalized)[0]
+        if pair_sel is not None:
+            values = values.index_select(0, pair_sel)
         n_rep = n_rows // values.shape[0]
         fused_vloss = on_gpu and fused.value_loss_usable(values) and values.shape[0] * n_rep == n_rows
         if values.shape[0] != n_rows and not fused_vloss:
@@ -326,10 +332,11 @@ class MAPPOTrainer:
         info = {"value_loss": 0.0, "policy_loss": 0.0, "dist_entropy": 0.0, "actor_grad_norm": 0.0,
                 "critic_grad_norm": 0.0, "ratio": 0.0}
         acc = torch.zeros(6, dtype=torch.float64, device=ptu.device)
+        recurrent = self._use_recurrent_policy or self._use_naive_recurrent
+        if self.num_mini_batch > 1 and not recurrent:
+            return self._train_mini_batches(buffer, advantages, update_actor, info)
         chunked = self.update_chunk_steps > 0 or getattr(buffer, "compact", False) or getattr(buffer, "structured", False)
         if chunked:
-            if self.num_mini_batch != 1:
-                raise NotImplementedError("chunked / compact-state updates are full-batch (num_mini_batch: 1)")
             if self.update_chunk_steps <= 0:   # rows are regenerated per chunk: keep them small; features are tiny
                 self.update_chunk_steps = buffer.episode_length if getattr(buffer, "structured", False) else 10
             # No [rows, hidden] activation of a chunk may reach 2^31 elements: beyond that a torch kernel of the backward pass
@@ -359,7 +366,6 @@ class MAPPOTrainer:
                 info[k] = v
             return info
         cached = None
-        recurrent = self._use_recurrent_policy or self._use_naive_recurrent
         if self.cache_normalized_inputs and self.num_mini_batch == 1 and not recurrent:
             with torch.no_grad():   # parameter-free: (x - mean) / sqrt(var + eps), once for all epochs
                 full = next(buffer.feed_forward_generator(advantages, 1, dedup_critic=self.dedup_critic))
@@ -381,6 +387,28 @@ class MAPPOTrainer:
         acc /= (self.ppo_epoch * self.num_mini_batch)
         vals = self._global_metrics(acc).tolist()   # the only host sync of the update
         for k, v in zip(("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"), vals):
+            info[k] = v
+        return info
+
+    def _train_mini_batches(self, buffer, advantages, update_actor, info):
+        """num_mini_batch > 1 with a feed-forward policy (mappo.py:203-213 over shared_buffer.py:239-279): every epoch one
+        permutation of the T*E*N agent rows, cut into num_mini_batch row sets; one ppo_update -- ValueNorm update on that
+        set's returns (Q11), losses as means over the set, clip, Adam -- per set.  Same code for every storage mode: the
+        buffer hands out rows, regenerated rows or state features (SharedReplayBuffer.minibatch_rows).
+        `self.minibatch_perms` (a list, consumed front to back) injects the permutations; otherwise torch.randperm on the CPU
+        generator, which is what the reference draws from."""
+        acc = torch.zeros(6, dtype=torch.float64, device=ptu.device)
+        n_updates = 0
+        for _ in range(self.ppo_epoch):
+            perm = self.minibatch_perms.pop(0) if getattr(self, "minibatch_perms", None) else None
+            for sample in buffer.feed_forward_generator(advantages, self.num_mini_batch, dedup_critic=self.dedup_critic, perm=perm):
+                vl, cgn, pl, ent, agn, imp = self.ppo_update(sample, update_actor)
+                acc += torch.stack([vl.detach().double(), pl.detach().double(), ent.detach().double(), agn.double(), cgn.double(),
+                                    imp.detach().mean().double()])
+                n_updates += 1
+        acc /= n_updates
+        for k, v in zip(("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"),
+                        self._global_metrics(acc).tolist()):
             info[k] = v
         return info
 

@@ -404,33 +404,91 @@ class SharedReplayBuffer(object):
                             self.returns.view(T + 1, E * N), self.advantages_raw.view(T, E * N))
 
     # ---- sampling -----------------------------------------------------------------------------------------------
-    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None, dedup_critic=False):
+    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None, dedup_critic=False, perm=None):
         """shared_buffer.py:219-279.  Yields the reference's 12-tuple of [B, .] tensors (device).
-        dedup_critic: `share_obs_batch` carries ONE row per (step, env) -- mini-batches are then drawn
-        over (step, env) pairs and contain all N agents of each pair."""
+        One mini-batch (the shipped setting): the whole batch in storage order, without the randperm gather (every loss is
+        a mean over the batch, order-free).  More than one: the reference's mini-batches -- one permutation of the
+        T*E*N agent rows (torch.randperm on the CPU generator, like the reference draws it, so the same seed selects the
+        same rows; `perm` injects one), cut into num_mini_batch row sets of batch_size // num_mini_batch rows
+        (`minibatch_rows`).  Works on every storage mode: row storage gathers rows, a state-only buffer gathers env states.
+        dedup_critic: `share_obs_batch` carries ONE row per (step, env) pair the mini-batch touches."""
         T, E, N = self.episode_length, self.n_rollout_threads, self.num_agents
         num_mini_batch = num_mini_batch or 1
-        if self.compact:
-            raise RuntimeError("compact buffer: the batch is visited with chunk_sample() (ppo_update_chunked)")
-        rows = lambda x: x.reshape(T * E * N, -1)
-        adv = torch.as_tensor(advantages).to(self.device, torch.float32)
         if num_mini_batch == 1 and mini_batch_size is None:
+            if self.compact:
+                raise RuntimeError("compact buffer: the full batch is visited with chunk_sample() (ppo_update_chunked)")
+            rows = lambda x: x.reshape(T * E * N, -1)
+            adv = torch.as_tensor(advantages).to(self.device, torch.float32)
             so = self.share_obs_env[:-1].reshape(T * E, -1) if dedup_critic else self.share_obs[:-1].reshape(T * E * N, -1)
             yield (so, rows(self.obs[:-1]), None, None, rows(self.actions), rows(self.value_preds[:-1]),
                    rows(self.returns[:-1]), rows(self.masks[:-1]), rows(self.active_masks[:-1]),
                    rows(self.action_log_probs), rows(adv), None)
             return
-        pairs = T * E
-        per = mini_batch_size // N if mini_batch_size else pairs // num_mini_batch
-        perm = torch.randperm(pairs, device=self.device)
-        pr = lambda x: x.reshape(pairs, N, -1)
+        batch_size = T * E * N
+        if mini_batch_size is None:
+            if batch_size < num_mini_batch:
+                raise ValueError("PPO requires n_rollout_threads (%d) * max_ep_len (%d) * num_agents (%d) >= num_mini_batch (%d)"
+                                 % (E, T, N, num_mini_batch))
+            mini_batch_size = batch_size // num_mini_batch
+        perm = torch.randperm(batch_size) if perm is None else torch.as_tensor(perm).reshape(-1).long()
         for i in range(num_mini_batch):
-            idx = perm[i * per:(i + 1) * per]
-            g = lambda x: pr(x)[idx].reshape(idx.numel() * N, -1)
-            so_env = self.share_obs_env[:-1].reshape(pairs, -1)[idx]
-            so = so_env if dedup_critic else so_env.unsqueeze(1).expand(-1, N, -1).reshape(idx.numel() * N, -1)
-            yield (so, g(self.obs[:-1]), None, None, g(self.actions), g(self.value_preds[:-1]), g(self.returns[:-1]),
-                   g(self.masks[:-1]), g(self.active_masks[:-1]), g(self.action_log_probs), g(adv), None)
+            yield self.minibatch_rows(advantages, perm[i * mini_batch_size:(i + 1) * mini_batch_size], dedup_critic)
+
+    def features_of_pairs(self, pairs):
+        """Policy-input features (dcc_obs_features) of the (step, env) states `pairs` (indices into the T*E flattening)."""
+        T, E = self.episode_length, self.n_rollout_threads
+        g = lambda a: a[:-1].reshape((T * E,) + tuple(a.shape[2:]))[pairs].contiguous()
+        return self._with_gemm_inputs(self._featurize(g(self.state_pos), g(self.state_vel), g(self.state_energy), g(self.state_done)))
+
+    def rows_of_pairs(self, pairs):
+        """Observation rows [n, N, D] of the (step, env) states `pairs`, regenerated from the stored state (dcc_obs_expand)."""
+        T, E = self.episode_length, self.n_rollout_threads
+        g = lambda a: a[:-1].reshape((T * E,) + tuple(a.shape[2:]))[pairs].contiguous()
+        out = torch.empty(pairs.numel(), self.num_agents, self.obs_dim, dtype=torch.float32, device=self.device)
+        self._expand(g(self.state_pos), g(self.state_vel), g(self.state_energy), g(self.state_done), out)
+        return out
+
+    def minibatch_rows(self, advantages, rows, dedup_critic=False):
+        """The reference's mini-batch for the agent rows `rows` -- indices into the (t, e, n) flattening of the T*E*N rows,
+        what `sampler` holds at shared_buffer.py:239-240 -- as its 12-tuple (:258-279).
+        A row (t, e, n) needs agent n's observation of state (t, e) and the centralised observation of that state.  Neither is
+        gathered N times over: the (step, env) pairs the rows touch are made unique (`pairs`, sorted), and
+          * row storage:      obs_batch = the rows themselves; share_obs_batch = one row per touched pair (dedup_critic) or per
+                              agent row (the reference's layout);
+          * state-only:       the touched states are gathered (32N + 5M bytes each) and their rows regenerated
+                              (dcc_obs_expand), then as above;
+          * structured input: obs_batch = share_obs_batch = the features of the touched states (dcc_obs_features).
+        When a batch entry is per pair instead of per row the tuple gets a 13th element (row_sel, pair_sel): index vectors that
+        pick each row's actor output out of the [pairs*N] outputs (None: obs_batch is per row already) and each row's value
+        out of the [pairs] critic outputs (MAPPOTrainer._forward_losses applies them; the gradient flows through the gather)."""
+        T, E, N = self.episode_length, self.n_rollout_threads, self.num_agents
+        B = T * E * N
+        rows = torch.as_tensor(rows).reshape(-1).to(self.device, torch.long)
+        adv = torch.as_tensor(advantages).to(self.device, torch.float32)
+        g = lambda x: x.reshape(B, -1)[rows]
+        tail = (g(self.actions), g(self.value_preds[:-1]), g(self.returns[:-1]), g(self.masks[:-1]), g(self.active_masks[:-1]),
+                g(self.action_log_probs), g(adv), None)
+        pair, agent = rows // N, rows % N
+        if self.structured:
+            if not dedup_critic:
+                raise NotImplementedError("structured input evaluates the centralised critic once per env (dedup_critic)")
+            pairs, inv = torch.unique(pair, return_inverse=True)
+            f = self.features_of_pairs(pairs)
+            return (f, f, None, None) + tail + ((inv * N + agent, inv),)
+        if self.compact:
+            pairs, inv = torch.unique(pair, return_inverse=True)
+            table = self.rows_of_pairs(pairs)
+            obs = table.view(pairs.numel() * N, -1)[inv * N + agent]
+            so_env = table.view(pairs.numel(), -1)
+            if dedup_critic:
+                return (so_env, obs, None, None) + tail + ((None, inv),)
+            return (so_env[inv], obs, None, None) + tail
+        obs = self.obs[:-1].reshape(B, -1)[rows]
+        so_env = self.share_obs_env[:-1].reshape(T * E, -1)
+        if dedup_critic:
+            pairs, inv = torch.unique(pair, return_inverse=True)
+            return (so_env[pairs], obs, None, None) + tail + ((None, inv),)
+        return (so_env[pair], obs, None, None) + tail
 
     # ---- recurrent generators (shared_buffer.py:281-487) ----------------------------------------------------------------
     # The reference builds every mini-batch with Python loops over chunks / env columns and np.stack on host arrays.

@@ -74,7 +74,7 @@ class HipCoverageVecEnv:
         self.action_space = [Box(-1.0, 1.0, (2,), np.float32) for _ in range(N)]
         self.observation_space = [Box(-inf, inf, (D,), np.float32) for _ in range(N)]
         self.share_observation_space = [Box(-inf, inf, (N * D,), np.float32) for _ in range(N)]
-        self._out = None
+        self._out = self._out64 = None
         self._closed = False
         # numpy surface: results leave the device through PINNED staging buffers (a pageable `.cpu()` of the 44 MB of
         # observations of a c2 step runs at 1.7 GB/s = 27 ms; pinned: 33 GB/s = 1.3 ms).  reuse_host_buffers: return views of
@@ -113,7 +113,7 @@ class HipCoverageVecEnv:
         if self._pin is None:
             E, N, D = self.n_envs, self.n_agents, self.obs_dim
             mk = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
-            self._pin = [dict(obs=mk((E, N, D), torch.float32), reward=mk((E,), torch.float32), done=mk((E,), torch.uint8),
+            self._pin = [dict(obs=mk((E, N, D), torch.float32), reward64=mk((E,), torch.float64), done=mk((E,), torch.uint8),
                               coverage=mk((E,), torch.float32)) for _ in range(2)]
         pin = self._pin[self._flip]
         self._flip ^= 1
@@ -133,10 +133,13 @@ class HipCoverageVecEnv:
             a = a.astype(np.float32)
         if a.shape != (self.n_envs, self.n_agents, 2):
             raise ValueError("actions must be [n_envs, n_agents, 2], got %s" % (a.shape,))
-        out = self.step_device(torch.from_numpy(a).to(self.device))   # a copy: the caller's array is never mutated
-        h = self._host({k: out[k] for k in ("obs", "reward", "done", "coverage")})
+        if self._out64 is None:        # the env's own float64 reward (dcc_env_out.reward64), what wrappers.py:161-165 hands back
+            self._out64 = torch.empty(self.n_envs, dtype=torch.float64, device=self.device)
+        out = self.step_device(torch.from_numpy(a).to(self.device),   # a copy: the caller's array is never mutated
+                               extra_out=dict(reward64=self._out64))
+        h = self._host({k: out[k] for k in ("obs", "reward64", "done", "coverage")})
         obs = h["obs"].astype(self.obs_dtype, copy=False)
-        rew = h["reward"].astype(np.float64)
+        rew = h["reward64"]
         done = h["done"].astype(bool)
         E, N = self.n_envs, self.n_agents
         rewards = np.repeat(rew[:, None, None], N, axis=1)               # [E,N,1]  (wrappers.py:165)

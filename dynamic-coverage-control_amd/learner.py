@@ -266,8 +266,7 @@ class Learner:
         r_envs.reset_device(r_buffer.obs_slot(0))
         if r_buffer.store_state:
             r_buffer.set_state_slot(0, r_envs.env.get_state())
-        r_buffer.masks[0].fill_(1.0)
-        r_buffer.step = 0
+        r_buffer.step = 0          # masks[0] is left as after_update set it (the last slot's), like the reference
 
     @torch.no_grad()
     def collect(self, cur_step, r_buffer):
@@ -307,6 +306,7 @@ class Learner:
         value from the networks, then a = mean + std * eps, log pi(a), and the writes into the buffer's action /
         log-prob / value slots of this step (include/dcc_mlp.h: dcc_rollout_sample).  Returns the action slot."""
         import dcc_hip
+        from algos.algo_utils.distributions import standard_normal
         self.trainer.prep_rollout()
         E, N = r_buffer.n_rollout_threads, self.n_agents
         if r_buffer.structured:
@@ -316,7 +316,7 @@ class Learner:
             x_critic = r_buffer.share_obs_env_at(cur_step)
         mean = self.policy.actor._mean(x_actor)
         value = self.policy.critic(x_critic)[0]
-        eps = torch.randn_like(mean)
+        eps = standard_normal(mean.shape, mean.dtype, mean.device)
         logstd = self.policy.actor.act.action_out.logstd._bias.view(-1)
         dcc_hip.rollout_sample(mean, logstd, eps, value.view(E), r_buffer.actions[cur_step], r_buffer.action_log_probs[cur_step],
                                r_buffer.value_preds[cur_step], N)

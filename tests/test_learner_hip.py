@@ -40,7 +40,8 @@ def test_vec_env_numpy_surface_matches_reference_contract():
         obs, rew, done, infos = env.step(a)
         assert np.array_equal(a, a0)                        # the caller's actions are not mutated (Q2)
         assert rew.shape == (c["E"], 4, 1) and done.shape == (c["E"], 4) and done.dtype == bool
-        np.testing.assert_allclose(rew[:, 0, 0], z["reward"][t], rtol=1e-5, atol=1e-5)
+        assert rew.dtype == np.float64                      # the env's own float64 reward (wrappers.py:161-165), not a rounded float32
+        np.testing.assert_allclose(rew[:, 0, 0], z["reward"][t], rtol=1e-12, atol=1e-9)
         assert np.array_equal(done[:, 0], z["done"][t].astype(bool))
         assert len(infos) == c["E"]
         np.testing.assert_allclose([i["coverage_rate"] for i in infos], z["coverage"][t], atol=1e-6)

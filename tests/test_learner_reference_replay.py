@@ -1,0 +1,184 @@
+"""-m gpu: this package's `Learner.train()` replays a multi-iteration trajectory of the REFERENCE's own orchestrator.
+
+tests/golden/learner_ref_e{1,2}.npz were written by tools/gen_golden_learner.py, which imports
+/root/reference/uav_dcc_control/learner.py and runs `Learner(cfg).train()` unmodified for 4 iterations (shipped 4 UAV x 20 PoI
+scenario, T = 40, hidden 32, ppo_epoch 15, eval rollout every 2nd iteration; E = 1 -> DummyVecEnv, E = 2 -> SubprocVecEnv),
+recording the Gaussian noise of every `collect`.  Here the same configuration drives this package's Learner with that noise
+injected (algos/algo_utils/distributions.set_noise_source) and every quantity the reference's loop produced is compared:
+
+  per rollout   actions, log-probs, rewards, masks (bit-exact), value predictions, GAE returns, observations in the buffer,
+                the `rollout()` metrics dict (reward, coverage_rate)                                   learner.py:178-214,278-287
+  per iteration lr after lr_decay, `rl_update()`'s dict, ValueNorm state (15 EMA updates per iteration, Q11), per-tensor
+                parameter DELTAS of the iteration, masks[0] after after_update                          learner.py:132-175,292-300
+
+The run is free: parameters are set once (iteration 0) and never re-synchronised with the fixture, so errors compound over the
+4 iterations the way they would in a real run.  Two storage configurations: the shipped default (compact state + structured
+first layers, no observation rows anywhere) and the reference-like row storage.  Tolerances are stated next to each check;
+the achieved maxima are printed (pytest -s) and quoted in DESIGN.md section 2.
+"""
+import json
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import GOLDEN, PKG
+
+pytestmark = pytest.mark.gpu
+
+# keys this package adds to the reference's configuration (config/algo_config/mappo.yaml, last block) or gives another default
+OWN_KEYS = {"double_surrogate", "dedup_critic", "cache_normalized_inputs", "use_hip_graph", "structured_input", "compact_obs",
+            "tuned_gemms", "update_chunk_steps"}
+
+
+def _shipped_cfg(ref_cfg, **over):
+    """This package's three YAMLs merged like train.py does, then the generator's overrides; every key of the reference's
+    merged configuration must come out with the reference's value (save_gifs is the one documented difference: no viewer)."""
+    cfg = {}
+    for f in ("config/env_config/dcc.yaml", "config/algo_config/mappo.yaml", "config/expt.yaml"):
+        cfg.update(yaml.safe_load(open(os.path.join(PKG, f))))
+    for k in ("n_rollout_threads", "max_ep_len", "algo_hidden_size", "n_iters", "eval_interval", "save_model", "log_wandb"):
+        cfg[k] = ref_cfg[k]
+    for k, v in ref_cfg.items():
+        if k in ("save_gifs",):
+            continue
+        assert k in cfg, "reference key %s missing from the shipped configuration" % k
+        assert cfg[k] == v or str(cfg[k]) == str(v), "key %s: %r here, %r in the reference run" % (k, cfg[k], v)
+    cfg.update(over)
+    return Namespace(**cfg)
+
+
+class _Track(object):
+    """max of |got - want| / scale per named quantity over the whole run (printed at the end)."""
+
+    def __init__(self):
+        self.worst = {}
+
+    def close(self, name, got, want, tol, scale=None):
+        got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+        assert got.shape == want.shape, "%s: shape %s vs %s" % (name, got.shape, want.shape)
+        s = float(np.abs(want).max()) if scale is None else float(scale)
+        err = float(np.abs(got - want).max()) / max(s, 1e-30)
+        key = name.split("@")[0]
+        self.worst[key] = max(self.worst.get(key, 0.0), err)
+        assert err <= tol, "%s: max error %.3e of scale %.3e exceeds %.1e" % (name, err, s, tol)
+
+
+def _set_params(module, Z, prefix):
+    sd = module.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            v.copy_(torch.from_numpy(Z[prefix + k]).to(v.device))
+    return sd
+
+
+@pytest.mark.parametrize("storage", ["shipped", "rows"])
+@pytest.mark.parametrize("E", [1, 2])
+def test_learner_replays_the_reference_learner(E, storage, capsys):
+    import utils.pytorch_utils as ptu
+    from algos.algo_utils import distributions
+    from algos.algo_utils.structured import invalidate_folded_weights
+    Z = np.load(os.path.join(GOLDEN, "learner_ref_e%d.npz" % E))
+    ref_cfg = json.loads(str(Z["cfg_json"]))
+    E_, N, M, T, H, n_iters, n_roll = [int(x) for x in Z["dims"]]
+    assert E_ == E
+    over = dict(use_hip_graph=False)          # the injected noise replaces the in-graph philox stream
+    if storage == "rows":
+        over.update(structured_input=False, compact_obs=False)
+    ptu.set_gpu_mode(True, 0)
+    from learner import Learner
+    lr = Learner(_shipped_cfg(ref_cfg, **over))
+    assert lr.rl_buffer.compact == (storage == "shipped") and lr.rl_buffer.structured == (storage == "shipped")
+    _set_params(lr.policy.actor, Z, "init/actor/")
+    _set_params(lr.policy.critic, Z, "init/critic/")
+    invalidate_folded_weights(lr.policy.actor, lr.policy.critic)
+
+    trk = _Track()
+    st = {"k": 0, "iter": 0, "draws": 0, "cur": None}
+    prev = {"a": {k: v.clone() for k, v in lr.policy.actor.state_dict().items()},
+            "c": {k: v.clone() for k, v in lr.policy.critic.state_dict().items()},
+            "ra": {k: Z["init/actor/" + k] for k in lr.policy.actor.state_dict()},
+            "rc": {k: Z["init/critic/" + k] for k in lr.policy.critic.state_dict()}}
+
+    def noise(shape, dtype, device):         # one draw per collect: the reference's eps of rollout k, step t
+        eps = st["cur"][st["draws"]]
+        st["draws"] += 1
+        return torch.from_numpy(eps.reshape(shape)).to(device=device, dtype=dtype)
+
+    orig_rollout, orig_update, orig_decay = lr.rollout, lr.rl_update, lr.trainer.policy.lr_decay
+
+    def lr_decay(episode, episodes):
+        orig_decay(episode, episodes)
+        st["iter"] = episode
+        for name, opt in (("lr_actor", lr.policy.actor_optimizer), ("lr_critic", lr.policy.critic_optimizer)):
+            trk.close("lr@%d" % episode, opt.param_groups[0]["lr"], Z["i%d/%s" % (episode, name)], 1e-12, scale=5e-4)
+
+    def rollout(r_buffer, r_envs, is_render=False, iter_=0):
+        k = st["k"]
+        pre = "r%d/" % k
+        assert k < n_roll and int(Z[pre + "kind"]) == (0 if r_buffer is lr.rl_buffer else 1), "rollout order differs"
+        assert int(Z[pre + "iter"]) == st["iter"]
+        Eb = r_buffer.n_rollout_threads
+        st["cur"], st["draws"] = Z[pre + "eps"].reshape(T, Eb * N, 2), 0
+        info = orig_rollout(r_buffer, r_envs, is_render, iter_)
+        assert st["draws"] == T, "one noise draw per collect"
+        g = lambda name: getattr(r_buffer, name).cpu().numpy()
+        np.testing.assert_array_equal(g("masks"), Z[pre + "masks"], err_msg=pre + "masks")               # bit-exact
+        assert float(Z[pre + "masks"][1:].min()) == 0.0                                                  # an episode ended
+        trk.close("actions@%d" % k, g("actions"), Z[pre + "actions"], 2e-5)
+        trk.close("action_log_probs@%d" % k, g("action_log_probs"), Z[pre + "action_log_probs"], 2e-5)
+        trk.close("rewards@%d" % k, g("rewards"), Z[pre + "rewards"], 1e-5)
+        trk.close("value_preds@%d" % k, g("value_preds"), Z[pre + "value_preds"], 2e-5)
+        trk.close("returns@%d" % k, g("returns"), Z[pre + "returns"], 1e-5)
+        obs = torch.stack([torch.as_tensor(r_buffer.obs[t]) for t in range(T + 1)]).cpu().numpy()   # rows / regenerated from state
+        trk.close("obs@%d" % k, obs, Z[pre + "obs"], 2e-5, scale=1.0)
+        trk.close("info_reward@%d" % k, info["reward"], Z[pre + "info_reward"], 1e-5)
+        trk.close("info_coverage_rate@%d" % k, info["coverage_rate"], Z[pre + "info_coverage_rate"], 1e-6, scale=1.0)
+        st["k"] += 1
+        return info
+
+    def rl_update():
+        info = orig_update()
+        i = st["iter"]
+        pre = "i%d/" % i
+        for key in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"):
+            # policy_loss is a difference of O(1) terms that nearly cancel (|policy_loss| ~ 1e-2 and 0 on the lr = 0 iteration)
+            trk.close("info_%s@%d" % (key, i), info[key], Z[pre + "info_" + key], 1e-4,
+                      scale=max(abs(float(Z[pre + "info_" + key])), 0.1 if key == "policy_loss" else 0.0))
+        vn = lr.trainer.value_normalizer
+        trk.close("vn_mean@%d" % i, vn.running_mean.cpu().numpy(), Z[pre + "vn_mean"], 1e-5)
+        trk.close("vn_mean_sq@%d" % i, vn.running_mean_sq.cpu().numpy(), Z[pre + "vn_mean_sq"], 1e-5)
+        trk.close("vn_debias@%d" % i, vn.debiasing_term.cpu().numpy(), Z[pre + "vn_debias"], 1e-6)
+        np.testing.assert_array_equal(lr.rl_buffer.masks[0].cpu().numpy(), Z[pre + "masks0"])
+        for tag, mod, rtag in (("a", lr.policy.actor, "actor/"), ("c", lr.policy.critic, "critic/")):
+            for name, v in mod.state_dict().items():
+                d_ref = Z[pre + rtag + name].astype(np.float64) - prev["r" + tag][name].astype(np.float64)
+                d_got = (v.double() - prev[tag][name].double()).cpu().numpy()
+                scale = float(np.abs(d_ref).max())
+                if scale == 0.0:            # lr = 0 (last iteration of the linear schedule): nothing may move
+                    assert float(np.abs(d_got).max()) == 0.0, "%s%s moved on the lr = 0 iteration" % (rtag, name)
+                else:
+                    trk.close("delta_%s%s@%d" % (rtag, name, i), d_got, d_ref, 1e-2, scale=scale)
+                trk.close("param_%s%s@%d" % (rtag, name, i), v.cpu().numpy(), Z[pre + rtag + name], 1e-4,
+                          scale=max(float(np.abs(Z[pre + rtag + name]).max()), 1e-2))
+                prev[tag][name] = v.clone()
+                prev["r" + tag][name] = Z[pre + rtag + name]
+        return info
+
+    lr.rollout, lr.rl_update, lr.trainer.policy.lr_decay = rollout, rl_update, lr_decay
+    old = distributions.set_noise_source(noise)
+    try:
+        lr.train()
+    finally:
+        distributions.set_noise_source(old)
+        ptu.set_gpu_mode(False)
+    assert st["k"] == n_roll and st["iter"] == n_iters
+    with capsys.disabled():
+        print("\n[learner replay E=%d %s] worst relative errors: " % (E, storage)
+              + ", ".join("%s %.1e" % (k, v) for k, v in sorted(trk.worst.items()) if not k.startswith(("delta_", "param_")))
+              + "; parameter deltas %.1e, parameters %.1e" % (
+                  max(v for k, v in trk.worst.items() if k.startswith("delta_")),
+                  max(v for k, v in trk.worst.items() if k.startswith("param_"))))

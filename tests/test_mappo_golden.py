@@ -8,7 +8,9 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, check_param_deltas
+
+DELTA_TOL = 3e-4      # post-update parameters as UPDATES: of max|delta| per tensor (achieved on the CPU: 3.0e-5, see the run summary)
 
 Z = np.load(os.path.join(GOLDEN, "mappo_small.npz"))
 N, E, T, D, A, H = 4, 3, 16, 20, 2, 32
@@ -161,11 +163,17 @@ def test_train_matches_reference(dedup, cache):
     info = tr.train(buf, update_actor=True)
     for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"):
         np.testing.assert_allclose(info[k], float(Z["info_" + k]), rtol=2e-4, atol=1e-6, err_msg=k)
-    for pre, mod in (("actor2/", pol.actor), ("critic2/", pol.critic)):
-        for k, v in mod.state_dict().items():
-            np.testing.assert_allclose(v.numpy(), Z[pre + k], rtol=1e-3, atol=2e-5, err_msg=pre + k)
+    _check_updates(pol, "train[dedup=%s,cache=%s]" % (dedup, cache))
     np.testing.assert_allclose(tr.value_normalizer.running_mean.numpy(), Z["vn1_mean"], rtol=1e-5)
     np.testing.assert_allclose(tr.value_normalizer.debiasing_term.numpy(), Z["vn1_debias"], rtol=1e-6)
+
+
+def _check_updates(pol, label, tol=DELTA_TOL):
+    """Post-update parameters as UPDATES (conftest.check_param_deltas) + the absolute window as a second line."""
+    for pre0, pre1, mod in (("actor/", "actor2/", pol.actor), ("critic/", "critic2/", pol.critic)):
+        before = {k[len(pre0):]: Z[k] for k in Z.files if k.startswith(pre0)}
+        after = {k[len(pre1):]: Z[k] for k in Z.files if k.startswith(pre1)}
+        check_param_deltas(mod, before, after, tol, "mappo_small " + label + " " + pre1[:-2], abs_tol=2e-5)
 
 
 def test_surrogate_doubling_flag():
@@ -199,27 +207,35 @@ def test_buffer_gae_has_no_cpu_path():
 
 @pytest.mark.parametrize("dedup", [False, True])
 def test_mini_batch_generator_partitions_the_rollout(dedup):
-    """num_mini_batch > 1: mini-batches are drawn over (step, env) pairs, contain all N agents
-    of each pair, and together cover every row exactly once; the critic rows stay aligned with the agent rows."""
+    """num_mini_batch > 1 follows the reference's feed_forward_generator (shared_buffer.py:239-279): one
+    permutation of the T*E*N agent rows drawn with torch.randperm on the CPU generator, cut into num_mini_batch row sets;
+    every field is the gather of those rows, the critic rows stay aligned with the agent rows."""
     cfg = make_cfg(num_mini_batch=3, dedup_critic=dedup)
     buf = _filled_buffer(cfg)
-    adv = torch.arange(T * E * N, dtype=torch.float32).view(T, E, N, 1)     # row id as the advantage
+    B = T * E * N
+    adv = torch.arange(B, dtype=torch.float32).view(T, E, N, 1)     # row id as the advantage
     seen = []
     torch.manual_seed(0)
-    for s in buf.feed_forward_generator(adv, 3, dedup_critic=dedup):
+    want = torch.randperm(B)                                          # what the reference's generator would draw after this seed
+    torch.manual_seed(0)
+    for i, s in enumerate(buf.feed_forward_generator(adv, 3, dedup_critic=dedup)):
         share, obs, acts, ids = s[0], s[1], s[4], s[10].view(-1).long()
-        assert obs.shape[0] == (T * E // 3) * N and ids.numel() == obs.shape[0]
-        assert share.shape[0] == (obs.shape[0] // N if dedup else obs.shape[0])
-        # rows really are the rows the ids name
-        np.testing.assert_array_equal(obs.numpy(), Z["buf_obs"][:-1].reshape(T * E * N, D)[ids.numpy()])
-        np.testing.assert_array_equal(acts.numpy(), Z["buf_actions"].reshape(T * E * N, A)[ids.numpy()])
-        pair = ids.view(-1, N)
-        assert bool((pair // N == pair[:, :1] // N).all())                  # all N agents of a (step, env) pair
-        so = Z["buf_obs"][:-1].reshape(T * E, S)[(pair[:, 0] // N).numpy()]
-        np.testing.assert_array_equal(share.numpy() if dedup else share.numpy()[::N], so)
+        assert torch.equal(ids, want[i * (B // 3):(i + 1) * (B // 3)])                 # the reference's row sets, in its order
+        np.testing.assert_array_equal(obs.numpy(), Z["buf_obs"][:-1].reshape(B, D)[ids.numpy()])
+        np.testing.assert_array_equal(acts.numpy(), Z["buf_actions"].reshape(B, A)[ids.numpy()])
+        np.testing.assert_array_equal(s[5].numpy(), buf.value_preds[:-1].reshape(B, 1)[ids].numpy())
+        np.testing.assert_array_equal(s[9].numpy(), buf.action_log_probs.reshape(B, -1)[ids].numpy())
+        so_rows = Z["buf_obs"][:-1].reshape(T * E, S)[(ids // N).numpy()]            # the centralised row of each agent row
+        if dedup:                                                                      # one row per touched (step, env) pair + selectors
+            row_sel, pair_sel = s[12]
+            assert row_sel is None and share.shape[0] == ids.div(N, rounding_mode="floor").unique().numel()
+            np.testing.assert_array_equal(share[pair_sel].numpy(), so_rows)
+        else:                                                                          # the reference's 12-tuple exactly
+            assert len(s) == 12
+            np.testing.assert_array_equal(share.numpy(), so_rows)
         seen.append(ids)
     allids = torch.cat(seen)
-    assert allids.numel() == (T * E // 3) * 3 * N and allids.unique().numel() == allids.numel()
+    assert allids.numel() == (B // 3) * 3 and allids.unique().numel() == allids.numel()
 
 
 def test_train_with_two_mini_batches_runs():
@@ -244,9 +260,7 @@ def test_chunked_update_matches_reference(dedup, chunk):
     info = tr.train(buf, update_actor=True)
     for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"):
         np.testing.assert_allclose(info[k], float(Z["info_" + k]), rtol=2e-4, atol=1e-6, err_msg=k)
-    for pre, mod in (("actor2/", pol.actor), ("critic2/", pol.critic)):
-        for k, v in mod.state_dict().items():
-            np.testing.assert_allclose(v.numpy(), Z[pre + k], rtol=1e-3, atol=2e-5, err_msg=pre + k)
+    _check_updates(pol, "chunked[dedup=%s,chunk=%d]" % (dedup, chunk))
     np.testing.assert_allclose(tr.value_normalizer.running_mean.numpy(), Z["vn1_mean"], rtol=1e-5)
     np.testing.assert_allclose(tr.value_normalizer.debiasing_term.numpy(), Z["vn1_debias"], rtol=1e-6)
 
@@ -287,9 +301,7 @@ def test_compact_buffer_update_matches_reference():
     assert len(calls) == n_chunks * cfg.ppo_epoch and max(calls) == 4 * E     # one chunk of observations at a time
     for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"):
         np.testing.assert_allclose(info[k], float(Z["info_" + k]), rtol=2e-4, atol=1e-6, err_msg=k)
-    for pre, mod in (("actor2/", pol.actor), ("critic2/", pol.critic)):
-        for k, v in mod.state_dict().items():
-            np.testing.assert_allclose(v.numpy(), Z[pre + k], rtol=1e-3, atol=2e-5, err_msg=pre + k)
+    _check_updates(pol, "compact-buffer")
 
 
 def test_compact_buffer_answers_the_reference_attribute_names():

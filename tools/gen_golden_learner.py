@@ -1,0 +1,158 @@
+"""Generate tests/golden/learner_ref_e<E>.npz: a multi-iteration trajectory of the REFERENCE's own orchestrator,
+`Learner(cfg).train()` imported from /root/reference/uav_dcc_control/learner.py (learner.py:132-300: train -> lr_decay ->
+rollout = warmup + [collect -> step -> insert] x T + compute -> rl_update -> after_update, eval rollouts every
+eval_interval).  Container-only (needs /root/reference); the outputs are data.  Re-run:
+
+    python tools/gen_golden_learner.py 1      # n_rollout_threads 1 -> DummyVecEnv        (envs/wrappers.py:204-236)
+    python tools/gen_golden_learner.py 2      # n_rollout_threads 2 -> SubprocVecEnv      (envs/wrappers.py:133-202)
+
+Nothing of the reference is modified: the class is driven through its public `train()`; the only instrumentation is
+  * a wrapper around the bound `learner.rollout` / `learner.rl_update` that snapshots the buffers / parameters after each call,
+  * a forward hook on the actor's DiagGaussian head that records (mean, std) of every `collect` so that the Gaussian noise
+    eps = (action - mean) / std the reference drew can be stored (the replaying test injects it in place of its own RNG).
+Third-party container modules absent from this image (gym, omegaconf, wandb, imageio) are in-memory / test stand-ins with no
+arithmetic (SURVEY.md 8c iii).
+
+Configuration = the reference's three YAMLs merged like train.py:12-19 does, with only: n_rollout_threads E, max_ep_len 40,
+algo_hidden_size 32, n_iters 4, eval_interval 2, save_model / log_wandb off.  The shipped scenario (4 UAV x 20 PoI) and every
+other key (ppo_epoch 15, num_mini_batch 1, lr 5e-4 with linear decay -> the 4th iteration runs with lr 0) are untouched.
+Before training, the action-mean bias is set to (+1.2, 0.15): the swarm drifts east and leaves the arena around step 33-36, so
+each rollout holds an episode end + auto-reset (masks = 0, the value bootstrap cut, the reset observation in the next slot).
+
+Contents (k = rollout call in order of execution, i = iteration 1..4):
+  cfg_json                         the merged configuration
+  init/actor/*, init/critic/*      parameters the run starts from
+  r<k>/kind (0 train, 1 eval), r<k>/iter, r<k>/eps [T,E,N,2] f64, r<k>/mean, r<k>/std, r<k>/actions, r<k>/action_log_probs,
+  r<k>/rewards, r<k>/masks, r<k>/value_preds, r<k>/returns, r<k>/obs [T+1,E,N,D] f32, r<k>/info_reward, r<k>/info_coverage_rate,
+  r<k>/vn_* ValueNorm state the returns were computed with
+  i<i>/lr_actor, lr_critic (after lr_decay), i<i>/info_* (rl_update's dict), i<i>/vn_* (after the update),
+  i<i>/actor/*, i<i>/critic/* (parameters after the update), i<i>/masks0 (slot 0 after after_update)
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/uav_dcc_control"
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "..", "tests", "_standin"))        # omegaconf stand-in (PyYAML-backed container)
+from ref_harness import _install_gym_stub  # noqa: E402
+
+
+def _stub_modules():
+    _install_gym_stub()
+    for name in ("wandb", "imageio"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+
+
+def sd_np(module, prefix, out):
+    for k, v in module.state_dict().items():
+        out[prefix + k] = v.detach().cpu().numpy().copy()
+
+
+def vn_np(vn, prefix, out):
+    out[prefix + "vn_mean"] = vn.running_mean.numpy().copy()
+    out[prefix + "vn_mean_sq"] = vn.running_mean_sq.numpy().copy()
+    out[prefix + "vn_debias"] = vn.debiasing_term.numpy().copy()
+
+
+def main(E):
+    _stub_modules()
+    os.chdir(REF)                         # the reference resolves ./config/... and ./envs/... relative to its own directory
+    sys.path.insert(0, REF)
+    from omegaconf import OmegaConf
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(False)
+    from learner import Learner
+
+    cfg = OmegaConf.merge(OmegaConf.load("./config/env_config/dcc.yaml"), OmegaConf.load("./config/algo_config/mappo.yaml"),
+                          OmegaConf.load("./config/expt.yaml"))
+    cfg.log_wandb = False
+    cfg.save_model = False
+    cfg.n_rollout_threads = E
+    cfg.max_ep_len = 40
+    cfg.algo_hidden_size = 32
+    cfg.n_iters = 4
+    cfg.eval_interval = 2
+    torch.set_num_threads(1)
+    learner = Learner(cfg)
+    out = {"cfg_json": np.array(json.dumps(OmegaConf.to_container(cfg, resolve=True), default=str))}
+
+    with torch.no_grad():
+        learner.policy.actor.act.action_out.fc_mean.bias.copy_(torch.tensor([1.2, 0.15]))
+    sd_np(learner.policy.actor, "init/actor/", out)
+    sd_np(learner.policy.critic, "init/critic/", out)
+
+    rec = {"on": False, "mean": [], "std": []}
+
+    def hook(mod, inp, dist):
+        if rec["on"]:
+            rec["mean"].append(dist.mean.detach().numpy().copy())
+            rec["std"].append(dist.stddev.detach().numpy().copy())
+
+    learner.policy.actor.act.action_out.register_forward_hook(hook)
+    T, N = learner.max_ep_len, learner.n_agents
+    state = {"k": 0, "iter": 0}
+    orig_rollout, orig_update = learner.rollout, learner.rl_update
+    orig_decay = learner.trainer.policy.lr_decay
+
+    def lr_decay(episode, episodes):
+        orig_decay(episode, episodes)
+        state["iter"] = episode
+        out["i%d/lr_actor" % episode] = np.array(learner.policy.actor_optimizer.param_groups[0]["lr"], np.float64)
+        out["i%d/lr_critic" % episode] = np.array(learner.policy.critic_optimizer.param_groups[0]["lr"], np.float64)
+
+    def rollout(r_buffer, r_envs, is_render=False, iter_=0):
+        rec["on"], rec["mean"], rec["std"] = True, [], []
+        pre = "r%d/" % state["k"]
+        vn_np(learner.trainer.value_normalizer, pre, out)         # the state compute() denormalises with
+        info = orig_rollout(r_buffer, r_envs, is_render, iter_)
+        rec["on"] = False
+        Eb = r_buffer.n_rollout_threads
+        mean = np.stack(rec["mean"]).reshape(T, Eb, N, -1).astype(np.float64)
+        std = np.stack(rec["std"]).reshape(T, Eb, N, -1).astype(np.float64)
+        actions = r_buffer.actions.copy()
+        out.update({pre + "kind": np.array(0 if r_buffer is learner.rl_buffer else 1), pre + "iter": np.array(state["iter"]),
+                    pre + "eps": (actions.astype(np.float64) - mean) / std, pre + "mean": mean.astype(np.float32),
+                    pre + "std": std.astype(np.float32), pre + "actions": actions,
+                    pre + "action_log_probs": r_buffer.action_log_probs.copy(), pre + "rewards": r_buffer.rewards.copy(),
+                    pre + "masks": r_buffer.masks.copy(), pre + "value_preds": r_buffer.value_preds.copy(),
+                    pre + "returns": r_buffer.returns.copy(), pre + "obs": r_buffer.obs.copy(),
+                    pre + "info_reward": np.array(float(info["reward"])),
+                    pre + "info_coverage_rate": np.array(float(info["coverage_rate"]))})
+        assert np.array_equal(r_buffer.share_obs[:, :, 0], r_buffer.obs.reshape(T + 1, Eb, -1))
+        state["k"] += 1
+        return info
+
+    def rl_update():
+        info = orig_update()
+        pre = "i%d/" % state["iter"]
+        for k, v in info.items():
+            out[pre + "info_" + k] = np.array(float(v))
+        vn_np(learner.trainer.value_normalizer, pre, out)
+        sd_np(learner.policy.actor, pre + "actor/", out)
+        sd_np(learner.policy.critic, pre + "critic/", out)
+        out[pre + "masks0"] = learner.rl_buffer.masks[0].copy()
+        return info
+
+    learner.rollout, learner.rl_update = rollout, rl_update
+    learner.trainer.policy.lr_decay = lr_decay
+    learner.train()
+
+    out["dims"] = np.array([E, N, learner.cfg.num_pois, T, learner.cfg.algo_hidden_size, learner.cfg.n_iters, state["k"]])
+    path = os.path.join(HERE, "..", "tests", "golden", "learner_ref_e%d.npz" % E)
+    np.savez_compressed(path, **out)
+    ends = [int((out["r%d/masks" % k][1:, :, 0, 0] == 0).sum()) for k in range(state["k"])]
+    print("wrote", os.path.normpath(path), os.path.getsize(path) // 1024, "KB; rollouts:", state["k"], "kinds:",
+          [int(out["r%d/kind" % k]) for k in range(state["k"])], "episode ends per rollout:", ends)
+    print("rollout infos:", [(round(float(out["r%d/info_reward" % k]), 3), round(float(out["r%d/info_coverage_rate" % k]), 3))
+                             for k in range(state["k"])])
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 2)

@@ -25,7 +25,11 @@ sys.path.insert(0, HERE)
 from ref_harness import make_reference_env  # noqa: E402  (installs the gym stub, puts the reference on sys.path)
 
 REF = "/root/reference/uav_dcc_control"
-CASES = {"small": (4, 20, 3, 34, 32), "n8m64": (8, 64, 2, 31, 32), "n12m24": (12, 24, 2, 20, 32)}     # N, M, E, T, H
+CASES = {"small": (4, 20, 3, 34, 32), "n8m64": (8, 64, 2, 31, 32), "n12m24": (12, 24, 2, 20, 32),     # N, M, E, T, H
+         # [, num_mini_batch]: the reference's feed_forward_generator with more than one mini-batch (shared_buffer.py:239-279):
+         # per epoch one torch.randperm over the T*E*N agent rows, cut into num_mini_batch row sets, one ppo_update (and one
+         # ValueNorm update, Q11) per set.  The permutations the run drew are stored as perm<epoch>.
+         "small_mb2": (4, 20, 3, 34, 32, 2), "n8m64_mb3": (8, 64, 2, 31, 32, 3)}
 
 
 class Box:
@@ -50,7 +54,8 @@ def main(case="small"):
     from algos.mappo import MAPPOPolicy, MAPPOTrainer
     from buffer.shared_buffer import SharedReplayBuffer
 
-    N, M, E, T, H = CASES[case]
+    N, M, E, T, H = CASES[case][:5]
+    MB = CASES[case][5] if len(CASES[case]) > 5 else 1
     A = 2
     D = 4 + 2 * (N - 1) + 5 * M
     S = N * D
@@ -59,7 +64,7 @@ def main(case="small"):
         cfg.update(yaml.safe_load(open(os.path.join(REF, f))))
     for k in ("actor_lr", "critic_lr", "opti_eps"):
         cfg[k] = float(cfg[k])
-    cfg.update(num_agents=N, n_rollout_threads=E, max_ep_len=T, algo_hidden_size=H, ppo_epoch=2)
+    cfg.update(num_agents=N, n_rollout_threads=E, max_ep_len=T, algo_hidden_size=H, ppo_epoch=2, num_mini_batch=MB)
     cfg = Namespace(**cfg)
     torch.manual_seed(17); np.random.seed(17)
     policy = MAPPOPolicy(cfg, Box(D), Box(S), Box(A))
@@ -126,7 +131,22 @@ def main(case="small"):
     out["adv_norm"] = (adv - np.nanmean(adv)) / (np.nanstd(adv) + 1e-5)
     trainer.prep_training()
     torch.manual_seed(3)
-    info = trainer.train(buf, update_actor=True)
+    perms, randperm = [], torch.randperm
+
+    def recording_randperm(*a, **k):       # torch's function, not the reference's: note every permutation the generator draws
+        p = randperm(*a, **k)
+        perms.append(p.numpy().copy())
+        return p
+
+    torch.randperm = recording_randperm
+    try:
+        info = trainer.train(buf, update_actor=True)
+    finally:
+        torch.randperm = randperm
+    assert len(perms) == cfg.ppo_epoch and all(len(p) == T * E * N for p in perms)
+    if MB > 1:
+        for i, p in enumerate(perms):
+            out["perm%d" % i] = p.astype(np.int64)
     for k, v in info.items():
         out["info_" + k] = np.array(float(v))
     for k, v in policy.actor.state_dict().items():
@@ -135,7 +155,7 @@ def main(case="small"):
         out["critic2/" + k] = v.numpy().copy()
     out.update(vn1_mean=vn.running_mean.numpy().copy(), vn1_mean_sq=vn.running_mean_sq.numpy().copy(),
                vn1_debias=vn.debiasing_term.numpy().copy())
-    out["dims"] = np.array([N, M, E, T, A, H, D])
+    out["dims"] = np.array([N, M, E, T, A, H, D] + ([MB] if MB > 1 else []))
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KB; episode ends:", int((masks[:, :, 0, 0] == 0).sum()),
           "info:", {k: round(float(v), 5) for k, v in info.items()})

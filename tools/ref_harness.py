@@ -71,6 +71,10 @@ def _install_gym_stub():
     reg.load = lambda *a, **k: None
     envs.registration = reg
     gym.Env, gym.Space, gym.spaces, gym.envs = Env, Space, spaces, envs
+    # picklable by reference (the reference's SubprocVecEnv sends the space objects through a Pipe, envs/wrappers.py:128)
+    for cls, mod in ((Env, "gym"), (Space, "gym"), (Box, "gym.spaces"), (Discrete, "gym.spaces"), (Tuple, "gym.spaces"),
+                     (EnvSpec, "gym.envs.registration")):
+        cls.__module__, cls.__qualname__ = mod, cls.__name__
     sys.modules.update({"gym": gym, "gym.spaces": spaces, "gym.spaces.box": box,
                         "gym.envs": envs, "gym.envs.registration": reg})
 
