@@ -66,37 +66,50 @@ def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, E=256, K=150, budget_all_
     from oracle import oracle
     oracle.build()
     cores = _host_threads()
-    sub = 10                                           # steps per C call: the granularity of the time checks
+    # steps per C call = the granularity of the time checks: about 0.1 s of single-thread work per call (the restatement costs
+    # ~75 ns per UAV x PoI pair and env-step: c2 10 steps, c4 2, c5 1), so that the budgets below are real bounds at every shape
+    pair_s = 75e-9 * N * M
+    sub = int(max(1, min(10, round(0.1 / (E * pair_s)))))
+    # single-thread leg at very large shapes: fewer envs, so that even one call stays near half a second
+    E1 = int(max(8, min(E, 0.5 / (sub * pair_s))))
 
     def make(n_envs):
         e = oracle.CpuTwinEnv(n_envs, N, M, poi, r_cover, r_comm, crs, cfs)
         e.reset()
         return e, e.alloc_out(sub, obs=True, assign=True)
 
-    # ---- single thread: all E envs, K steps (or as many as fit the budget)
-    o, out1 = make(E)
+    # ---- single thread: E1 envs, K steps (or as many as fit the budget)
+    o, out1 = make(E1)
     t0 = time.perf_counter()
     k1 = 0
     while k1 < K and (k1 == 0 or time.perf_counter() - t0 < budget_single_s):
-        o.rollout(sub, seed=0, step0=k1, env0=0, env_total=E, out=out1)
-        k1 += sub
+        n = min(sub, K - k1)
+        o.rollout(n, seed=0, step0=k1, env0=0, env_total=E1, out=out1)
+        k1 += n
     dt1 = time.perf_counter() - t0
-    rate1 = E * k1 * N / dt1
+    rate1 = E1 * k1 * N / dt1
     o.close()
-    # ---- all threads: thread i owns the contiguous env range [i * E / cores, (i + 1) * E / cores), whole passes of K steps
+    del o, out1                                        # (c5: 1.7 GB of rows) before the per-thread buffers are built
+    # ---- all threads: thread i owns the contiguous env range [i * E / cores, (i + 1) * E / cores); passes of K steps, the last one
+    # cut at the deadline (at least one call per thread): what is counted is the steps actually done
     bounds = [E * i // cores for i in range(cores + 1)]
     envs = [make(bounds[i + 1] - bounds[i]) if bounds[i + 1] > bounds[i] else None for i in range(cores)]
-    passes = [0] * cores
+    steps_done = [0] * cores
     deadline = [0.0]
 
     def work(i):
         if envs[i] is None:
             return
         e, out = envs[i]
-        while passes[i] == 0 or time.perf_counter() < deadline[0]:
+        p = 0
+        while True:
             for k in range(0, K, sub):                # ctypes releases the GIL inside the C call
-                e.rollout(sub, seed=1 + passes[i], step0=k, env0=bounds[i], env_total=E, out=out)
-            passes[i] += 1
+                if steps_done[i] > 0 and time.perf_counter() >= deadline[0]:
+                    return
+                n = min(sub, K - k)
+                e.rollout(n, seed=1 + p, step0=k, env0=bounds[i], env_total=E, out=out)
+                steps_done[i] += n
+            p += 1
 
     ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
     t0 = time.perf_counter()
@@ -106,11 +119,12 @@ def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, E=256, K=150, budget_all_
     for t in ths:
         t.join()
     dt = time.perf_counter() - t0
-    env_steps = sum((bounds[i + 1] - bounds[i]) * passes[i] * K for i in range(cores))
+    env_steps = sum((bounds[i + 1] - bounds[i]) * steps_done[i] for i in range(cores))
     value = env_steps * N / dt
     for ev in envs:
         if ev is not None:
             ev[0].close()
+    live = [sd for sd, ev in zip(steps_done, envs) if ev is not None]
     try:
         model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
@@ -118,12 +132,14 @@ def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, E=256, K=150, budget_all_
     return {"value": value, "unit": "agent-env-steps/s", "cores": cores, "kind": "port",
             "sample": "oracle/dcc_env_cpu.c (the `_cpu` twins of include/dcc_env.h over the C restatement of the reference env, "
                       "float64): BASELINE.md 4.2 batch E = %d envs x K = %d steps of the %s workload (N=%d, M=%d%s), counter-based "
-                      "random actions, observation rows written.  All %d host threads (one contiguous env range each): %d-%d whole "
-                      "passes per thread in %.1f s = %d env-steps.  Single thread: %d of the %d steps of the %d envs in %.1f s = %.0f "
-                      "agent-env-steps/s.  Host CPU: %s" % (E, K, label, N, M, ", pull force on" if cfs > 0 else "", cores,
-                                                           min(p for p, ev in zip(passes, envs) if ev is not None), max(passes), dt,
-                                                           env_steps, k1, K, E, dt1, rate1, model),
-            "value_1core": rate1, "batch_envs": E, "batch_steps": K, "single_thread_steps_done": k1}
+                      "random actions, observation rows written, %d step(s) per C call.  All %d host threads (one contiguous env range "
+                      "each, %.1f s budget, the last pass cut at the deadline): %d-%d steps per thread (%.2f-%.2f passes of %d) in %.1f s = "
+                      "%d env-steps.  Single thread (%.1f s budget): %d of the %d steps of %d envs in %.1f s = %.0f agent-env-steps/s.  "
+                      "Host CPU: %s" % (E, K, label, N, M, ", pull force on" if cfs > 0 else "", sub, cores, budget_all_s,
+                                        min(live), max(live), min(live) / K, max(live) / K, K, dt, env_steps, budget_single_s, k1, K, E1,
+                                        dt1, rate1, model),
+            "value_1core": rate1, "batch_envs": E, "batch_steps": K, "single_thread_steps_done": k1, "single_thread_envs": E1,
+            "steps_per_call": sub, "all_thread_steps_done": [min(live), max(live)]}
 
 
 def mappo_iterations(args, iters, warm_iters=2):
@@ -374,10 +390,19 @@ def _emit_json(res):
     with _EMIT_LOCK:
         if _EMITTED:
             return False
-        _EMITTED = True
+        line = None
+        for _ in range(5):      # a helper thread (watchdog / SIGTERM) may serialise while the main thread is adding a leg's result
+            try:
+                line = json.dumps(dict(res))
+                break
+            except RuntimeError:        # "dictionary changed size during iteration"
+                time.sleep(0.01)
+        if line is None:
+            line = json.dumps({k: res[k] for k in list(res) if not isinstance(res[k], dict)})      # the headline scalars at least
         out = _JSON_OUT or sys.stdout
-        out.write(json.dumps(res) + "\n")
+        out.write(line + "\n")
         out.flush()
+        _EMITTED = True
         return True
 
 
@@ -431,6 +456,7 @@ def main():
     ap.add_argument("--c3-iters", type=int, default=2, help="--mode env: timed MAPPO iterations of the c3 leg")
     ap.add_argument("--leg-place-tries", type=int, default=4, help="candidate output allocations timed per bounded leg (c2_strong / c4 / c5)")
     ap.add_argument("--c3-timeout", type=float, default=240.0, help="give up on the c3 leg after this many seconds")
+    ap.add_argument("--test-kill-rank-at-leg", default="", help=argparse.SUPPRESS)   # tests/test_bench_contract.py only: "<rank>:<leg>"
     ap.add_argument("--iters", type=int, default=2, help="--mode mappo: timed training iterations")
     ap.add_argument("--ppo-epoch", type=int, default=15)
     ap.add_argument("--no-graph", action="store_true", help="mappo: issue the rollout eagerly from Python")
@@ -651,10 +677,10 @@ def main():
                 if b and b[0] == signal.SIGTERM:
                     res.setdefault(current[0], {"error": "terminated by the launcher (SIGTERM) during this leg: another rank failed"})
                     emit()
-                    os._exit(0)
+                    os._exit(128 + signal.SIGTERM)      # the line is out, the job still failed
 
         threading.Thread(target=on_sigterm, daemon=True).start()
-        kill = os.environ.get("DCC_BENCH_KILL", "")        # test hook "<rank>:<leg>": that rank exits at the start of that leg
+        kill = args.test_kill_rank_at_leg or ""            # TEST-ONLY flag "<rank>:<leg>": that rank exits at the start of that leg
 
         def leg(key, fn):
             current[0] = key

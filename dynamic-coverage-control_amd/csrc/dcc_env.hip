@@ -1391,10 +1391,10 @@ struct dcc_env {
     uint8_t* d_done = nullptr;
     size_t lds_bytes = 0, lds_bytes_roles = 0, lds_bytes_split = 0;
     bool no_spec = false, no_roles = false, force_roles = false, no_split = false, force_split = false;
-    // create-time choice between the role-specialised and the fused kernel for obs-writing multi-step launches with one PoI
-    // per lane (which of the two streams faster depends on the box: DESIGN.md 4.1); tune_us: measured us per step of each
     int roles_envs_forced = 0;  // DCC_ROLES_ENVS = 1 / 2 (tests, A/B); 0 = by batch size
     int roles1_max = 1024;      // batches up to this many envs run one env per role-specialised workgroup (DCC_ROLES1_MAX)
+    // create-time choice between the role-specialised and the fused kernel for obs-writing multi-step launches with one PoI
+    // per lane (which of the two streams faster depends on the box: DESIGN.md 4.1); tune_us: measured us per step of each
     bool prefer_fused = false;
     int tuned = 0;              // 0: not measured (shape not eligible, disabled, or the measurement failed), 1: measured
     float tune_us[2] = {0.f, 0.f};   // [0] role-specialised, [1] fused
@@ -1577,7 +1577,14 @@ int fill_out(KParams& p, const dcc_env_out* out) {
 // golden case through both).  The env state is reset afterwards, i.e. left exactly as dcc_env_create leaves it.
 // The choice is a property of (device, shape): measured once per process and shape, reused by later dcc_env_create calls (every
 // test / every learner creates envs of the same few shapes), so that a library user pays the transient scratch allocation once.
-struct TuneKey { int dev, E, N, M; };
+// ... and of everything else that selects the two instantiations being timed: the FORCE template argument (pull force on: other
+// launch bounds / occupancy), generic vs compile-time-specialised (DCC_NO_SPEC), envs per role-specialised workgroup.
+struct TuneKey {
+    int dev, E, N, M, force, no_spec, roles_envs;
+    bool operator==(const TuneKey& o) const {
+        return dev == o.dev && E == o.E && N == o.N && M == o.M && force == o.force && no_spec == o.no_spec && roles_envs == o.roles_envs;
+    }
+};
 struct TuneVal { bool prefer_fused; float us[2]; };
 std::mutex g_tune_mu;
 std::vector<std::pair<TuneKey, TuneVal>> g_tune_cache;
@@ -1592,10 +1599,12 @@ void autotune_kernel_shape(dcc_env* e) {
     // trails the physics wave), which a short measurement would count against it: 64 steps keep that bias at 3 %.
     const int K = 64;
     if (step_bytes * K > kTuneScratchMax) return;
+    const TuneKey key{e->device, e->cfg.n_envs, e->cfg.n_agents, e->cfg.n_pois, e->base.use_force != 0, e->no_spec ? 1 : 0,
+                      (e->roles_envs_forced > 0) ? e->roles_envs_forced : (e->cfg.n_envs <= e->roles1_max ? 1 : 2)};
     {
         std::lock_guard<std::mutex> lk(g_tune_mu);
         for (const auto& kv : g_tune_cache)
-            if (kv.first.dev == e->device && kv.first.E == e->cfg.n_envs && kv.first.N == e->cfg.n_agents && kv.first.M == e->cfg.n_pois) {
+            if (kv.first == key) {
                 e->prefer_fused = kv.second.prefer_fused; e->tune_us[0] = kv.second.us[0]; e->tune_us[1] = kv.second.us[1]; e->tuned = 1;
                 return;
             }
@@ -1632,8 +1641,7 @@ void autotune_kernel_shape(dcc_env* e) {
         e->prefer_fused = best[1] < 0.94f * best[0];
         e->tuned = 1;
         std::lock_guard<std::mutex> lk(g_tune_mu);
-        g_tune_cache.push_back({TuneKey{e->device, e->cfg.n_envs, e->cfg.n_agents, e->cfg.n_pois},
-                                TuneVal{e->prefer_fused, {e->tune_us[0], e->tune_us[1]}}});
+        g_tune_cache.push_back({key, TuneVal{e->prefer_fused, {e->tune_us[0], e->tune_us[1]}}});
     } else {
         (void)hipGetLastError();
     }

@@ -410,11 +410,14 @@ class Learner:
     def load_checkpoint(self, path, strict_world=None):
         """Every rank reads the file and takes ITS OWN RNG streams and env shard (the replicated parts -- parameters,
         optimizer moments, ValueNorm, counters -- are identical on all ranks by construction).
-        A checkpoint written by a different number of ranks still carries everything that does NOT depend on the rank
-        count: it is loaded (e.g. to evaluate on one GPU a model trained on eight, or to continue on another node size)
-        with a warning; only the per-rank RNG streams and env-shard states are skipped -- the run then continues from this
-        process's own seed and from reset envs (every rollout starts with a reset anyway, Q9).  strict_world=True (cfg key
-        `resume_strict`) asks for the bit-exact continuation and raises instead."""
+        Job shape = (number of ranks, envs per rank).  Default rule (strict_world=None, cfg key `resume_strict` unset): a
+        checkpoint that still has iterations to run (ck.iter < n_iters) is a run being CONTINUED and must come from a job of
+        the same shape -- anything else raises, naming both shapes and the escape hatch; a finished one (ck.iter >= n_iters:
+        evaluation, parameter hand-over) loads leniently.  `resume_strict: false` (strict_world=False) always loads leniently:
+        everything that does not depend on the shape is restored (e.g. to evaluate on one GPU a model trained on eight, or to
+        fine-tune with fewer envs), only the per-rank RNG streams and env-shard states are skipped -- the run then continues
+        from this process's own seed and from reset envs (every rollout starts with a reset anyway, Q9) -- with a warning.
+        `resume_strict: true` always insists on the bit-exact continuation."""
         ck = torch.load(path, map_location="cpu", weights_only=False)
         if ck.get("format", 1) == 1:        # single-rank layout of the first format
             ck["ranks"] = [{k: ck[k] for k in ("rng_torch", "rng_numpy", "rng_cuda", "env_state")}]
@@ -429,8 +432,12 @@ class Learner:
         same_world = (ck["world_size"] == self.world and self.rank < len(ck["ranks"]) and
                       ck["ranks"][self.rank]["env_state"]["pos"].shape[0] == self.train_envs.n_envs)
         if not same_world and strict_world:
-            raise ValueError("checkpoint written by %d ranks, this job has %d (the env shards and RNG streams are per rank)"
-                             % (ck["world_size"], self.world))
+            raise ValueError("checkpoint %s (iteration %d of %d) was written by %d rank(s) with %d envs each; this job has %d rank(s) "
+                             "with %d envs each.  The env shards and RNG streams are per rank, so a bit-exact continuation needs "
+                             "the same job shape; set `resume_strict: false` to load parameters, optimizer moments, ValueNorm and "
+                             "counters only (RNG streams and env states start fresh)"
+                             % (path, int(ck["iter"]), int(self.n_iters), ck["world_size"],
+                                ck["ranks"][0]["env_state"]["pos"].shape[0], self.world, self.train_envs.n_envs))
         self.policy.actor.load_state_dict(ck["actor"]); self.policy.critic.load_state_dict(ck["critic"])
         self.policy.actor_optimizer.load_state_dict(ck["actor_optimizer"])
         self.policy.critic_optimizer.load_state_dict(ck["critic_optimizer"])

@@ -183,8 +183,8 @@ def test_checkpoint_of_another_job_size_loads_the_replicated_state(tmp_path):
     ck = str(tmp_path / "resume.pt")
     a.save_checkpoint(ck)
     d = Learner(_cfg(n_rollout_threads=8, seed=5, **kw))          # default: iteration 1 of 3 -> training would continue -> refuse
-    with pytest.raises(ValueError):
-        d.load_checkpoint(ck)
+    with pytest.raises(ValueError, match=r"1 rank\(s\) with 16 envs each; this job has 1 rank\(s\) with 8 envs each.*resume_strict: false"):
+        d.load_checkpoint(ck)                                      # same rank count, other shard size: both named, with the way out
     e = Learner(_cfg(n_rollout_threads=8, seed=5, **dict(kw, n_iters=1)))   # nothing left to train: the lenient hand-over
     with pytest.warns(UserWarning, match="per-rank RNG streams and env states are not"):
         e.load_checkpoint(ck)

@@ -55,16 +55,19 @@ class _Track(object):
     """max of |got - want| / scale per named quantity over the whole run (printed at the end)."""
 
     def __init__(self):
-        self.worst = {}
+        self.worst, self.failures = {}, []
 
     def close(self, name, got, want, tol, scale=None):
+        """Violations are collected, not raised: the run goes on, so one test run shows every quantity that is off and by how
+        much (the test fails at the end with the full list)."""
         got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
         assert got.shape == want.shape, "%s: shape %s vs %s" % (name, got.shape, want.shape)
         s = float(np.abs(want).max()) if scale is None else float(scale)
         err = float(np.abs(got - want).max()) / max(s, 1e-30)
         key = name.split("@")[0]
         self.worst[key] = max(self.worst.get(key, 0.0), err)
-        assert err <= tol, "%s: max error %.3e of scale %.3e exceeds %.1e" % (name, err, s, tol)
+        if not err <= tol:
+            self.failures.append("%s: max error %.3e of scale %.3e exceeds %.1e" % (name, err, s, tol))
 
 
 def _set_params(module, Z, prefix):
@@ -102,6 +105,7 @@ def test_learner_replays_the_reference_learner(E, storage, capsys):
             "c": {k: v.clone() for k, v in lr.policy.critic.state_dict().items()},
             "ra": {k: Z["init/actor/" + k] for k in lr.policy.actor.state_dict()},
             "rc": {k: Z["init/critic/" + k] for k in lr.policy.critic.state_dict()}}
+    init = {"a": dict(prev["ra"]), "c": dict(prev["rc"])}
 
     def noise(shape, dtype, device):         # one draw per collect: the reference's eps of rollout k, step t
         eps = st["cur"][st["draws"]]
@@ -128,15 +132,20 @@ def test_learner_replays_the_reference_learner(E, storage, capsys):
         g = lambda name: getattr(r_buffer, name).cpu().numpy()
         np.testing.assert_array_equal(g("masks"), Z[pre + "masks"], err_msg=pre + "masks")               # bit-exact
         assert float(Z[pre + "masks"][1:].min()) == 0.0                                                  # an episode ended
-        trk.close("actions@%d" % k, g("actions"), Z[pre + "actions"], 2e-5)
-        trk.close("action_log_probs@%d" % k, g("action_log_probs"), Z[pre + "action_log_probs"], 2e-5)
-        trk.close("rewards@%d" % k, g("rewards"), Z[pre + "rewards"], 1e-5)
-        trk.close("value_preds@%d" % k, g("value_preds"), Z[pre + "value_preds"], 2e-5)
-        trk.close("returns@%d" % k, g("returns"), Z[pre + "returns"], 1e-5)
+        # Iteration 1 runs on the fixture's own parameters: pure forward / env / GAE parity, <= 1e-5 relative (2e-5 for what comes
+        # straight out of the fp32 networks).  From iteration 2 on the parameters are this run's own (updates within 1 % of the
+        # reference's, see rl_update below), and that drift feeds back through actions -> positions -> rewards: 5x the window.
+        w = 1.0 if st["iter"] == 1 else 5.0
+        tag = "%s@%d" % ("" if st["iter"] == 1 else "_later", k)
+        trk.close("actions" + tag, g("actions"), Z[pre + "actions"], 2e-5 * w)
+        trk.close("action_log_probs" + tag, g("action_log_probs"), Z[pre + "action_log_probs"], 2e-5 * w)
+        trk.close("rewards" + tag, g("rewards"), Z[pre + "rewards"], 1e-5 * w)
+        trk.close("value_preds" + tag, g("value_preds"), Z[pre + "value_preds"], 2e-5 * w)
+        trk.close("returns" + tag, g("returns"), Z[pre + "returns"], 1e-5 * w)
         obs = torch.stack([torch.as_tensor(r_buffer.obs[t]) for t in range(T + 1)]).cpu().numpy()   # rows / regenerated from state
-        trk.close("obs@%d" % k, obs, Z[pre + "obs"], 2e-5, scale=1.0)
-        trk.close("info_reward@%d" % k, info["reward"], Z[pre + "info_reward"], 1e-5)
-        trk.close("info_coverage_rate@%d" % k, info["coverage_rate"], Z[pre + "info_coverage_rate"], 1e-6, scale=1.0)
+        trk.close("obs" + tag, obs, Z[pre + "obs"], 2e-5 * w, scale=1.0)
+        trk.close("info_reward" + tag, info["reward"], Z[pre + "info_reward"], 1e-5 * w)
+        trk.close("info_coverage_rate" + tag, info["coverage_rate"], Z[pre + "info_coverage_rate"], 1e-6, scale=1.0)
         st["k"] += 1
         return info
 
@@ -162,8 +171,10 @@ def test_learner_replays_the_reference_learner(E, storage, capsys):
                     assert float(np.abs(d_got).max()) == 0.0, "%s%s moved on the lr = 0 iteration" % (rtag, name)
                 else:
                     trk.close("delta_%s%s@%d" % (rtag, name, i), d_got, d_ref, 1e-2, scale=scale)
-                trk.close("param_%s%s@%d" % (rtag, name, i), v.cpu().numpy(), Z[pre + rtag + name], 1e-4,
-                          scale=max(float(np.abs(Z[pre + rtag + name]).max()), 1e-2))
+                # ... and the drift of the parameter itself since iteration 0, against the distance the reference has moved
+                c_ref = Z[pre + rtag + name].astype(np.float64) - init[tag][name].astype(np.float64)
+                trk.close("drift_%s%s@%d" % (rtag, name, i), v.double().cpu().numpy() - init[tag][name].astype(np.float64), c_ref,
+                          1e-2, scale=float(np.abs(c_ref).max()))
                 prev[tag][name] = v.clone()
                 prev["r" + tag][name] = Z[pre + rtag + name]
         return info
@@ -175,10 +186,10 @@ def test_learner_replays_the_reference_learner(E, storage, capsys):
     finally:
         distributions.set_noise_source(old)
         ptu.set_gpu_mode(False)
-    assert st["k"] == n_roll and st["iter"] == n_iters
     with capsys.disabled():
+        big = lambda pre: max(((v, k) for k, v in trk.worst.items() if k.startswith(pre)), default=(0.0, ""))
         print("\n[learner replay E=%d %s] worst relative errors: " % (E, storage)
-              + ", ".join("%s %.1e" % (k, v) for k, v in sorted(trk.worst.items()) if not k.startswith(("delta_", "param_")))
-              + "; parameter deltas %.1e, parameters %.1e" % (
-                  max(v for k, v in trk.worst.items() if k.startswith("delta_")),
-                  max(v for k, v in trk.worst.items() if k.startswith("param_"))))
+              + ", ".join("%s %.1e" % (k, v) for k, v in sorted(trk.worst.items()) if not k.startswith(("delta_", "drift_")))
+              + "; per-iteration parameter updates %.1e (%s), drift since iteration 0 %.1e (%s)" % (big("delta_") + big("drift_")))
+    assert st["k"] == n_roll and st["iter"] == n_iters
+    assert not trk.failures, "\n".join(trk.failures)
