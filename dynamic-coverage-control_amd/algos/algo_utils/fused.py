@@ -9,10 +9,13 @@
 All fall back to the plain torch formulation when the tensors are not float32 CUDA tensors (CPU tests,
 autocast) or the shape has no compiled variant; on a GPU box the library itself must load (dcc_hip raises).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
-ENABLED = True      # cfg.fused_mlp (learner.py) / tests toggle this
+# tests toggle this; DCC_FUSED_MLP=0 (diagnostic, tools/world8_ab.py) runs the plain torch formulations on the GPU as well
+ENABLED = os.environ.get("DCC_FUSED_MLP", "1") != "0"
 
 
 def _usable(t, H, HD=0):

@@ -54,7 +54,8 @@ for E in (512, 4096):
     a = torch.zeros(E, N, 2, device="cuda")
     for label, out in (("rows", env.alloc_out()), ("state only", {**{k: v for k, v in env.alloc_out(obs=False).items()}, **env.alloc_state_out()})):
         med, mn = timed(lambda: env.step(a, out), 200)
+        b2b = back_to_back(lambda: env.step(a, out))          # ONE measurement: the fraction below is of THIS time (r04 printed the
+        nbytes = dcc_hip.bytes_per_step(N, M, with_actions=True, with_obs=(label == "rows")) * E      # fraction of a second, slower run)
         print("E = %4d, K = 1, %-10s: %.2f us per step between events (min %.2f); %.2f us per step back to back (%.3f of 8 TB/s)"
-              % (E, label, med * 1e3, mn * 1e3, back_to_back(lambda: env.step(a, out)),
-                 (dcc_hip.bytes_per_step(N, M, with_actions=True, with_obs=(label == "rows")) * E) / (back_to_back(lambda: env.step(a, out)) * 1e-6) / 8e12))
+              % (E, label, med * 1e3, mn * 1e3, b2b, nbytes / (b2b * 1e-6) / 8e12))
     env.close()
