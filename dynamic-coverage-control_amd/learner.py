@@ -381,13 +381,15 @@ class Learner:
     # ---- faithful resume ------------------------------------------------------------
     def _rank_state(self):
         """What differs between the ranks of a multi-GPU job: the RNG streams (seeded seed + rank) and the env shard."""
-        return {"rng_torch": torch.get_rng_state(), "rng_numpy": np.random.get_state(),
+        b = self.rl_buffer      # slot 0 of the rollout buffer is what after_update carried over from the last rollout (masks, GRU states:
+        return {"rng_torch": torch.get_rng_state(), "rng_numpy": np.random.get_state(),       # shared_buffer.py:142-152)
                 "rng_cuda": torch.cuda.get_rng_state(ptu.device) if ptu.device.type == "cuda" else None,
-                "env_state": {k: v.cpu() for k, v in self.train_envs.env.get_state().items()}}
+                "env_state": {k: v.cpu() for k, v in self.train_envs.env.get_state().items()},
+                "slot0": {"masks": b.masks[0].cpu(), "rnn_states": b.rnn_states[0].cpu(), "rnn_states_critic": b.rnn_states_critic[0].cpu()}}
 
     def save_checkpoint(self, path):
         """Everything needed to continue a run bit-for-bit: parameters, both Adam states, ValueNorm, the
-        iteration counter, and PER RANK the RNG streams and the env-shard state (gathered to rank 0, which writes the
+        iteration counter, and PER RANK the RNG streams, the env-shard state and slot 0 of the rollout buffer (gathered to rank 0, which writes the
         file; COLLECTIVE in a multi-GPU job: every rank must call it).  (The reference pickles the policy object only:
         ValueNorm, iteration and RNG are lost, uav_dcc_control/algos/mappo.py:237-247.)"""
         ranks = [self._rank_state()]
@@ -449,6 +451,8 @@ class Learner:
             if mine["rng_cuda"] is not None and ptu.device.type == "cuda":
                 torch.cuda.set_rng_state(mine["rng_cuda"], ptu.device)
             self.train_envs.env.set_state(**mine["env_state"])
+            for k, v in mine.get("slot0", {}).items():         # (absent from checkpoints written before round 5)
+                getattr(self.rl_buffer, k)[0].copy_(v.to(ptu.device))
         else:
             import warnings
             self.resume_partial = True        # recorded in the iteration log of every rank

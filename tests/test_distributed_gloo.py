@@ -51,14 +51,23 @@ def _data(E):
                 returns=(vp * 90 - 250 + rs.normal(0, 20, vp.shape)).astype(np.float32))
 
 
-def _worker(rank, world, port, E, q):
+def _local_perms(rank, per, epochs=2):
+    """The permutations rank `rank` draws over its own T * per * N agent rows (mini-batch test)."""
+    g = torch.Generator().manual_seed(1000 + rank)
+    return [torch.randperm(16 * per * 4, generator=g) for _ in range(epochs)]
+
+
+def _worker(rank, world, port, E, q, mini_batches=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     per = E // world
-    pol, tr, buf = _build(E, 100 + rank, _data(E), rank * per, (rank + 1) * per)   # different init per rank ...
+    pol, tr, buf = _build(E, 100 + rank, _data(E), rank * per, (rank + 1) * per,      # different init per rank ...
+                          dict(num_mini_batch=mini_batches))
     pol.broadcast_parameters(0)                                                       # ... made identical here
+    if mini_batches > 1:
+        tr.minibatch_perms = _local_perms(rank, per)
     tr.prep_training()
     info = tr.train(buf)
     sd = {k: v.numpy().copy() for k, v in list(pol.actor.state_dict().items()) + list(pol.critic.state_dict().items())}
@@ -91,6 +100,48 @@ def test_two_rank_update_equals_single_process_full_batch():
             np.testing.assert_allclose(sd[k], ref[k].numpy(), rtol=2e-4, atol=2e-6, err_msg="rank%d %s" % (rank, k))
         np.testing.assert_allclose(vmean, tr.value_normalizer.running_mean.numpy(), rtol=1e-5)
     # replicas stay in lock-step
+    for k in ref:
+        assert np.array_equal(res[0][2][k], res[1][2][k]), k
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_mini_batches_equal_single_process_on_the_union():
+    """num_mini_batch = 2 on two ranks: every rank permutes ITS OWN rows; mini-batch i of the job is the union of the ranks' i-th
+    row sets, its loss the mean of the two equally sized per-rank means, ValueNorm sees the all-reduced batch moments.  One
+    process fed the union of those row sets (in its own row numbering) must end with the same parameters."""
+    E, N, T, MB = 4, 4, 16, 2
+    per = E // 2
+    locs = [_local_perms(r, per) for r in range(2)]
+    mb = T * per * N // MB
+
+    def to_global(rows, rank):          # local (t, e_l, n) -> global (t, rank * per + e_l, n)
+        t, e, n = rows // (per * N), (rows // N) % per, rows % N
+        return (t * E + rank * per + e) * N + n
+
+    perms = [torch.cat([torch.cat([to_global(locs[r][ep][i * mb:(i + 1) * mb], r) for r in range(2)]) for i in range(MB)])
+             for ep in range(2)]
+    assert all(p.unique().numel() == T * E * N for p in perms)
+    pol, tr, buf = _build(E, 100, _data(E), 0, E, dict(num_mini_batch=MB))
+    tr.minibatch_perms = perms
+    tr.prep_training()
+    info1 = tr.train(buf)
+    ref = {k: v.clone() for k, v in list(pol.actor.state_dict().items()) + list(pol.critic.state_dict().items())}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, E, q, MB)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, info, sd, vmean in res:
+        for k in info1:
+            np.testing.assert_allclose(info[k], info1[k], rtol=1e-4, atol=1e-6, err_msg=k)
+        for k in ref:
+            np.testing.assert_allclose(sd[k], ref[k].numpy(), rtol=2e-4, atol=2e-6, err_msg="rank%d %s" % (rank, k))
+        np.testing.assert_allclose(vmean, tr.value_normalizer.running_mean.numpy(), rtol=1e-5)
     for k in ref:
         assert np.array_equal(res[0][2][k], res[1][2][k]), k
 

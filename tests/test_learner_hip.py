@@ -163,6 +163,7 @@ def test_checkpoint_resume_is_bit_faithful(tmp_path):
     for (ka, va), (kb, vb) in zip(a.policy.actor.state_dict().items(), b.policy.actor.state_dict().items()):
         assert torch.equal(va, vb), ka
     assert torch.equal(a.trainer.value_normalizer.running_mean, b.trainer.value_normalizer.running_mean)
+    assert torch.equal(a.rl_buffer.masks, b.rl_buffer.masks)        # incl. slot 0 = the last slot of the rollout before the checkpoint
     ptu.set_gpu_mode(False)
 
 
