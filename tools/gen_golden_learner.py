@@ -5,6 +5,13 @@ eval_interval).  Container-only (needs /root/reference); the outputs are data.  
 
     python tools/gen_golden_learner.py 1      # n_rollout_threads 1 -> DummyVecEnv        (envs/wrappers.py:204-236)
     python tools/gen_golden_learner.py 2      # n_rollout_threads 2 -> SubprocVecEnv      (envs/wrappers.py:133-202)
+    python tools/gen_golden_learner.py 2 8 64 # the BASELINE c2 / c3 task size (8 UAV x 64 PoI) -> learner_ref_e2_n8m64.npz
+
+The third form needs the size-generalised scenario: the shipped one hard-codes 4 x 20 in make_world (coverage.py:40-41), so
+`scenarios.load` is pointed at tools/ref_harness.sized_scenario_class (ONLY make_world replaced) before the envs are built;
+DCEnv, MultiAgentEnv, CoverageWorld, the vec-env wrappers, make_env and the Learner run unmodified.  To keep the file small the
+observation rows are stored for the first rollout only (the env is pinned elsewhere; the states behind the rows are implied by
+actions + masks).
 
 Nothing of the reference is modified: the class is driven through its public `train()`; the only instrumentation is
   * a wrapper around the bound `learner.rollout` / `learner.rl_update` that snapshots the buffers / parameters after each call,
@@ -61,8 +68,9 @@ def vn_np(vn, prefix, out):
     out[prefix + "vn_debias"] = vn.debiasing_term.numpy().copy()
 
 
-def main(E):
+def main(E, N=None, M=None):
     _stub_modules()
+    sized = N is not None
     os.chdir(REF)                         # the reference resolves ./config/... and ./envs/... relative to its own directory
     sys.path.insert(0, REF)
     from omegaconf import OmegaConf
@@ -79,6 +87,13 @@ def main(E):
     cfg.algo_hidden_size = 32
     cfg.n_iters = 4
     cfg.eval_interval = 2
+    if sized:
+        cfg.num_agents, cfg.num_pois = N, M
+        from argparse import Namespace as _NS
+        from ref_harness import sized_scenario_class
+        import envs.mpe.multiagent.scenarios as scenarios
+        Sized = sized_scenario_class()
+        scenarios.load = lambda name: _NS(Scenario=Sized)      # what DCEnv.__init__ calls (uav_dcc.py:21); forked workers inherit it
     torch.set_num_threads(1)
     learner = Learner(cfg)
     out = {"cfg_json": np.array(json.dumps(OmegaConf.to_container(cfg, resolve=True), default=str))}
@@ -122,9 +137,11 @@ def main(E):
                     pre + "std": std.astype(np.float32), pre + "actions": actions,
                     pre + "action_log_probs": r_buffer.action_log_probs.copy(), pre + "rewards": r_buffer.rewards.copy(),
                     pre + "masks": r_buffer.masks.copy(), pre + "value_preds": r_buffer.value_preds.copy(),
-                    pre + "returns": r_buffer.returns.copy(), pre + "obs": r_buffer.obs.copy(),
+                    pre + "returns": r_buffer.returns.copy(),
                     pre + "info_reward": np.array(float(info["reward"])),
                     pre + "info_coverage_rate": np.array(float(info["coverage_rate"]))})
+        if not sized or state["k"] == 0:
+            out[pre + "obs"] = r_buffer.obs.copy()
         assert np.array_equal(r_buffer.share_obs[:, :, 0], r_buffer.obs.reshape(T + 1, Eb, -1))
         state["k"] += 1
         return info
@@ -145,7 +162,7 @@ def main(E):
     learner.train()
 
     out["dims"] = np.array([E, N, learner.cfg.num_pois, T, learner.cfg.algo_hidden_size, learner.cfg.n_iters, state["k"]])
-    path = os.path.join(HERE, "..", "tests", "golden", "learner_ref_e%d.npz" % E)
+    path = os.path.join(HERE, "..", "tests", "golden", "learner_ref_e%d%s.npz" % (E, "_n%dm%d" % (N, M) if sized else ""))
     np.savez_compressed(path, **out)
     ends = [int((out["r%d/masks" % k][1:, :, 0, 0] == 0).sum()) for k in range(state["k"])]
     print("wrote", os.path.normpath(path), os.path.getsize(path) // 1024, "KB; rollouts:", state["k"], "kinds:",
@@ -155,4 +172,4 @@ def main(E):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 2)
+    main(*[int(v) for v in sys.argv[1:4]] or [2])

@@ -91,27 +91,26 @@ def import_reference():
     return scenarios, CoverageWorld, Agent, Landmark, MultiAgentEnv
 
 
-def make_reference_env(N, M, r_cover, r_comm, comm_r_scale, comm_force_scale, extra_pois=None):
-    """Build the reference MultiAgentEnv at arbitrary (N, M).
-
-    Only `make_world` is replaced: it performs the same attribute assignments as
-    coverage.py:46-59 for N agents / M landmarks, builds CoverageWorld(comm_r_scale,
-    comm_force_scale) and sizes dist_mat NxN (CoverageWorld.py:11 hard-codes 4x4).
-    `extra_pois` ([k,2] f64) is appended to pos_pois.npy when M > 1000 (the file has 1000 rows).
-    """
+def sized_scenario_class(extra_pois=None):
+    """The reference Scenario with ONLY `make_world` replaced, constructed with the reference's own signature
+    (num_agents, num_pois, r_cover, r_comm, comm_r_scale, comm_force_scale -- what DCEnv.__init__ passes, uav_dcc.py:21-29):
+    make_world performs the same attribute assignments as coverage.py:46-59 for num_agents agents / num_pois landmarks, builds
+    CoverageWorld(comm_r_scale, comm_force_scale) and sizes dist_mat NxN (CoverageWorld.py:11 hard-codes 4x4).
+    `extra_pois` ([k,2] f64) is appended to pos_pois.npy when num_pois > 1000 (the file has 1000 rows)."""
     scenarios, CoverageWorld, Agent, Landmark, MultiAgentEnv = import_reference()
     ref_mod = scenarios.load("coverage.py")
 
     class SizedScenario(ref_mod.Scenario):
-        def __init__(self):
-            super().__init__(num_agents=N, num_pois=min(M, 1000), r_cover=r_cover, r_comm=r_comm,
+        def __init__(self, num_agents=4, num_pois=20, r_cover=0.25, r_comm=0.5, comm_r_scale=0.9, comm_force_scale=0.5):
+            super().__init__(num_agents=num_agents, num_pois=min(num_pois, 1000), r_cover=r_cover, r_comm=r_comm,
                              comm_r_scale=comm_r_scale, comm_force_scale=comm_force_scale)
-            if M > 1000:
-                assert extra_pois is not None and extra_pois.shape == (M - 1000, 2)
+            if num_pois > 1000:
+                assert extra_pois is not None and extra_pois.shape == (num_pois - 1000, 2)
                 self.pos_pois = np.concatenate([self.pos_pois, extra_pois], 0)
-            self.num_pois = M
+            self.num_pois = num_pois
 
         def make_world(self):
+            N, M = self.num_agents, self.num_pois
             world = CoverageWorld(comm_r_scale=self.comm_r_scale, comm_force_scale=self.comm_force_scale)
             world.collaborative = True
             world.agents = [Agent() for _ in range(N)]
@@ -134,7 +133,13 @@ def make_reference_env(N, M, r_cover, r_comm, comm_r_scale, comm_force_scale, ex
             self.reset_world(world)
             return world
 
-    sc = SizedScenario()
+    return SizedScenario
+
+
+def make_reference_env(N, M, r_cover, r_comm, comm_r_scale, comm_force_scale, extra_pois=None):
+    """Build the reference MultiAgentEnv at arbitrary (N, M) around `sized_scenario_class` (every arithmetic method unmodified)."""
+    scenarios, CoverageWorld, Agent, Landmark, MultiAgentEnv = import_reference()
+    sc = sized_scenario_class(extra_pois)(N, M, r_cover, r_comm, comm_r_scale, comm_force_scale)
     world = sc.make_world()
     env = MultiAgentEnv(world=world, reset_callback=sc.reset_world, reward_callback=sc.reward,
                         observation_callback=sc.observation, done_callback=sc.done)
