@@ -73,7 +73,10 @@ def test_single_env_dcenv_view():
     obs_n = env.reset()
     assert len(obs_n) == 4 and obs_n[0].shape == (110,)
     o, r, d, info = env.step(np.zeros((4, 2)))
-    assert abs(r[0] - (-56.51319293982027)) < 1e-3 and d == [False] * 4 and info["coverage_rate"] == 0.0
+    assert abs(r[0] - (-56.51319293982027)) < 1e-9 and d == [False] * 4 and info["coverage_rate"] == 0.0   # SURVEY Appendix B, float64
+    assert env.render("human") is None
+    frame = env.render("rgb_array")
+    assert len(frame) == 1 and frame[0].shape == (350, 350, 3) and frame[0].dtype == np.uint8
     env.close()
 
 
