@@ -159,7 +159,7 @@ def mappo_iterations(args, iters, warm_iters=2):
                max_ep_len=args.steps_per_launch, ppo_epoch=args.ppo_epoch, save_model=False, n_iters=1,
                comm_force_scale=args.comm_force_scale, r_comm=args.r_comm,
                use_hip_graph=not args.no_graph, compact_obs=not args.keep_rows, update_chunk_steps=args.update_chunk_steps,
-               structured_input=not args.no_structured_input)
+               structured_input=not args.no_structured_input, num_mini_batch=args.num_mini_batch)
     from learner import Learner
     lr = Learner(Namespace(**cfg))
 
@@ -212,6 +212,7 @@ def mappo_iterations(args, iters, warm_iters=2):
            "iters_warmup": warm_iters, "s_per_iter": dt / iters, "rollout_s_per_iter": tr / iters,
            "update_s_per_iter": tu / iters, "rollout_agent_env_steps_per_sec": world * E * N * T / (tr / iters),
            "hip_graph_rollout": not args.no_graph, "rows_stored": bool(args.keep_rows), "structured_input": structured,
+           "num_mini_batch": int(getattr(args, "num_mini_batch", 1)),
            "tuned_gemm_entries": lr.tuned_gemms,
            "tuned_gemm_warning": None if lr.tuned_gemms else (
                "0 entries of config/gemm_tunings_gfx950.csv are in use (its validators -- torch / ROCm / rocBLAS / hipBLASLt "
@@ -459,6 +460,7 @@ def main():
     ap.add_argument("--test-kill-rank-at-leg", default="", help=argparse.SUPPRESS)   # tests/test_bench_contract.py only: "<rank>:<leg>"
     ap.add_argument("--iters", type=int, default=2, help="--mode mappo: timed training iterations")
     ap.add_argument("--ppo-epoch", type=int, default=15)
+    ap.add_argument("--num-mini-batch", type=int, default=1, help="mappo: the reference's num_mini_batch (1 = the shipped full-batch update)")
     ap.add_argument("--no-graph", action="store_true", help="mappo: issue the rollout eagerly from Python")
     ap.add_argument("--keep-rows", action="store_true",
                     help="mappo: also store the observation rows in the rollout buffer (default: compact env state only)")

@@ -229,8 +229,10 @@ def env_gemm_inputs(feats, critic):
     return x
 
 
-def actor_trunk(base, layout, feats, head=None):
-    """MLPBase(obs rows) for the n*N agent rows described by feats -> [n*N, H] (or head(.) -> [n*N, A])."""
+def actor_trunk(base, layout, feats, head=None, row_sel=None):
+    """MLPBase(obs rows) for the n*N agent rows described by feats -> [n*N, H] (or head(.) -> [n*N, A]).
+    row_sel (row mini-batches, SharedReplayBuffer.minibatch_rows): indices into the n*N rows; only those rows go on past the
+    first block (whose per-env part is shared by an env's agents anyway) -> [len(row_sel), .]."""
     head_f, stats = feats["head"], feats["stats"]
     n, N, HD = head_f.shape
     w_h, w_env, s_w, c, eps = folded_weights(base, layout, 1)            # [H,HD], [H,pad8(2M+1)], [H], [H]
@@ -238,7 +240,7 @@ def actor_trunk(base, layout, feats, head=None):
     blk = base.mlp.fc1
     if isinstance(blk[1], nn.ReLU):   # one fused pass: the pre-activation never reaches memory (include/dcc_mlp.h)
         h = fused.actor_l1(head_f, g, stats if eps is not None else None, w_h, s_w, c, blk[2], eps, layout.D)
-        return _rest(base, h, head)
+        return _rest(base, h if row_sel is None else h.index_select(0, row_sel), head)
     z = F.linear(head_f.reshape(n * N, HD), w_h).view(n, N, -1) + g.unsqueeze(1)
     if eps is not None:
         mean = stats[..., 0]
@@ -246,7 +248,8 @@ def actor_trunk(base, layout, feats, head=None):
         z = rstd.to(z.dtype).unsqueeze(-1) * (z - mean.to(z.dtype).unsqueeze(-1) * s_w) + c
     else:
         z = z + c
-    return _rest(base, _tail(blk, z.reshape(n * N, -1)), head)
+    z = z.reshape(n * N, -1)
+    return _rest(base, _tail(blk, z if row_sel is None else z.index_select(0, row_sel)), head)
 
 
 def critic_trunk(base, layout, feats, head=None):

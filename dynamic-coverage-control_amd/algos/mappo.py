@@ -189,9 +189,7 @@ class MAPPOTrainer:
         actor = self.policy.actor
         on_gpu = ptu.device.type == "cuda"
         fused_loss = on_gpu and available_actions_batch is None and fused.policy_loss_usable(actions_batch, old_logp)
-        mean = actor._mean(obs_batch, prenormalized, rnn_states_batch, masks_batch)
-        if row_sel is not None:
-            mean = mean.index_select(0, row_sel)
+        mean = actor._mean(obs_batch, prenormalized, rnn_states_batch, masks_batch, row_sel=row_sel)
         if not fused_loss:  # (fused: surrogate, entropy and their gradients in one HIP pass over [B, A], dcc_ppo_policy_loss)
             action_log_probs, dist_entropy = actor.act.evaluate_actions(
                 None, actions_batch, available_actions_batch,

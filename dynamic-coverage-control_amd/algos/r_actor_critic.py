@@ -43,18 +43,22 @@ class R_Actor(nn.Module):
         self.obs_layout = None    # set by MAPPOPolicy.enable_structured_input
         self.to(device)
 
-    def _mean(self, obs, prenormalized=False, rnn_states=None, masks=None, want_states=False):
+    def _mean(self, obs, prenormalized=False, rnn_states=None, masks=None, want_states=False, row_sel=None):
         """Gaussian mean [B, A] = fc_mean(trunk(obs)) (the head is fused with the trunk's last block on the GPU).
         obs: rows [B, D], or the dict of compact features of B/N env states (algo_utils/structured.py).
-        Recurrent variants: fc_mean(rnn(trunk(obs), rnn_states, masks)); want_states also returns the new states."""
+        Recurrent variants: fc_mean(rnn(trunk(obs), rnn_states, masks)); want_states also returns the new states.
+        row_sel: keep only these of the rows `obs` describes (row mini-batches over per-env features: the selection is applied
+        right after the first block, so the 256 x 256 block and the head run on the selected rows only)."""
         head = self.act.action_out.fc_mean
         trunk_head = head if self.rnn is None else None
         if isinstance(obs, dict):
             if self.obs_layout is None:
                 raise RuntimeError("compact features passed to an actor without an observation layout")
-            out = structured.actor_trunk(self.base, self.obs_layout, obs, trunk_head)
+            out = structured.actor_trunk(self.base, self.obs_layout, obs, trunk_head, row_sel)
         else:
             obs = check(obs).to(**self.tpdv)
+            if row_sel is not None:
+                obs = obs.index_select(0, row_sel)
             out = self.base.forward_prenormalized(obs, trunk_head) if prenormalized else self.base(obs, trunk_head)
         if self.rnn is not None:
             feats, rnn_states = self.rnn(out, check(rnn_states).to(**self.tpdv), check(masks).to(**self.tpdv))

@@ -460,7 +460,9 @@ class SharedReplayBuffer(object):
           * structured input: obs_batch = share_obs_batch = the features of the touched states (dcc_obs_features).
         When a batch entry is per pair instead of per row the tuple gets a 13th element (row_sel, pair_sel): index vectors that
         pick each row's actor output out of the [pairs*N] outputs (None: obs_batch is per row already) and each row's value
-        out of the [pairs] critic outputs (MAPPOTrainer._forward_losses applies them; the gradient flows through the gather)."""
+        out of the [pairs] critic outputs (MAPPOTrainer._forward_losses applies them -- the row selection right after the
+        actor's first block, so its 256 x 256 block and head run on the mini-batch's rows only; the gradient flows through the
+        gathers)."""
         T, E, N = self.episode_length, self.n_rollout_threads, self.num_agents
         B = T * E * N
         rows = torch.as_tensor(rows).reshape(-1).to(self.device, torch.long)
