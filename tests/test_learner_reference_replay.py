@@ -1,9 +1,9 @@
 """-m gpu: this package's `Learner.train()` replays a multi-iteration trajectory of the REFERENCE's own orchestrator.
 
-tests/golden/learner_ref_e{1,2}.npz were written by tools/gen_golden_learner.py, which imports
+tests/golden/learner_ref_{e1,e2,e2_n8m64}.npz were written by tools/gen_golden_learner.py, which imports
 /root/reference/uav_dcc_control/learner.py and runs `Learner(cfg).train()` unmodified for 4 iterations (shipped 4 UAV x 20 PoI
-scenario, T = 40, hidden 32, ppo_epoch 15, eval rollout every 2nd iteration; E = 1 -> DummyVecEnv, E = 2 -> SubprocVecEnv),
-recording the Gaussian noise of every `collect`.  Here the same configuration drives this package's Learner with that noise
+scenario, T = 40, hidden 32, ppo_epoch 15, eval rollout every 2nd iteration; E = 1 -> DummyVecEnv, E = 2 -> SubprocVecEnv; and
+the 8 UAV x 64 PoI task of BASELINE c2 / c3 through the size-generalised scenario), recording the Gaussian noise of every `collect`.  Here the same configuration drives this package's Learner with that noise
 injected (algos/algo_utils/distributions.set_noise_source) and every quantity the reference's loop produced is compared:
 
   per rollout   actions, log-probs, rewards, masks (bit-exact), value predictions, GAE returns, observations in the buffer,
