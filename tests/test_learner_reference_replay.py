@@ -27,8 +27,6 @@ import yaml
 
 from conftest import GOLDEN, PKG
 
-pytestmark = pytest.mark.gpu
-
 # keys this package adds to the reference's configuration (config/algo_config/mappo.yaml, last block) or gives another default
 OWN_KEYS = {"double_surrogate", "dedup_critic", "cache_normalized_inputs", "use_hip_graph", "structured_input", "compact_obs",
             "tuned_gemms", "update_chunk_steps"}
@@ -79,11 +77,29 @@ def _set_params(module, Z, prefix):
     return sd
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("storage", ["shipped", "rows"])
 @pytest.mark.parametrize("fixture", ["e1", "e2", "e2_n8m64"])
 def test_learner_replays_the_reference_learner(fixture, storage, capsys):
     """e1 / e2: the shipped 4 UAV x 20 PoI task on 1 env (DummyVecEnv in the reference) / 2 envs (SubprocVecEnv); e2_n8m64: the
     BASELINE c2 / c3 task size, 8 UAV x 64 PoI, through the size-generalised scenario (tools/gen_golden_learner.py)."""
+    _replay(fixture, storage, True, capsys)
+
+
+@pytest.mark.parametrize("storage", ["rows", "state-only"])
+@pytest.mark.parametrize("fixture", ["e1", "e2", "e2_n8m64"])
+def test_orchestrator_replays_the_reference_learner_on_the_cpu(fixture, storage, capsys, oracle_mod):
+    """The same replay without a GPU: the package's Learner / vec-env / buffer / trainer on torch CPU tensors, with the `_cpu` twins
+    of the C-ABI standing in for the two device entry points (tests/_cpu_twin_backend.py).  Pins the host-side orchestration --
+    what learner.py:132-300 does between the kernels -- in the build container; the kernels themselves are the -m gpu run's job.
+    Row storage and the state-only buffer with regenerated rows (dcc_obs_expand_cpu); dense first layers (the structured ones
+    need dcc_obs_features, which has no twin)."""
+    from _cpu_twin_backend import cpu_twin_backend
+    with cpu_twin_backend():
+        _replay(fixture, storage, False, capsys)
+
+
+def _replay(fixture, storage, gpu, capsys):
     import utils.pytorch_utils as ptu
     from algos.algo_utils import distributions
     from algos.algo_utils.structured import invalidate_folded_weights
@@ -94,10 +110,12 @@ def test_learner_replays_the_reference_learner(fixture, storage, capsys):
     over = dict(use_hip_graph=False)          # the injected noise replaces the in-graph philox stream
     if storage == "rows":
         over.update(structured_input=False, compact_obs=False)
-    ptu.set_gpu_mode(True, 0)
+    elif storage == "state-only":
+        over.update(structured_input=False, compact_obs=True)
+    ptu.set_gpu_mode(gpu, 0)
     from learner import Learner
     lr = Learner(_shipped_cfg(ref_cfg, **over))
-    assert lr.rl_buffer.compact == (storage == "shipped") and lr.rl_buffer.structured == (storage == "shipped")
+    assert lr.rl_buffer.compact == (storage != "rows") and lr.rl_buffer.structured == (storage == "shipped")
     _set_params(lr.policy.actor, Z, "init/actor/")
     _set_params(lr.policy.critic, Z, "init/critic/")
     invalidate_folded_weights(lr.policy.actor, lr.policy.critic)
@@ -192,7 +210,7 @@ def test_learner_replays_the_reference_learner(fixture, storage, capsys):
         ptu.set_gpu_mode(False)
     with capsys.disabled():
         big = lambda pre: max(((v, k) for k, v in trk.worst.items() if k.startswith(pre)), default=(0.0, ""))
-        print("\n[learner replay %s %s] worst relative errors: " % (fixture, storage)
+        print("\n[learner replay %s %s %s] worst relative errors: " % (fixture, storage, "gpu" if gpu else "cpu")
               + ", ".join("%s %.1e" % (k, v) for k, v in sorted(trk.worst.items()) if not k.startswith(("delta_", "drift_")))
               + "; per-iteration parameter updates %.1e (%s), drift since iteration 0 %.1e (%s)" % (big("delta_") + big("drift_")))
     assert st["k"] == n_roll and st["iter"] == n_iters
