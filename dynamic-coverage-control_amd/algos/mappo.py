@@ -60,7 +60,7 @@ class MAPPOPolicy:
         if dist is None:
             return
         for p in list(self.actor.parameters()) + list(self.critic.parameters()):
-            dist.broadcast(p.data, src)
+            ptu.broadcast(p.data, src)
 
     def lr_decay(self, episode, episodes):
         update_linear_schedule(self.actor_optimizer, episode, episodes, self.actor_lr)
@@ -102,7 +102,7 @@ def _allreduce_start(opt):
     dist = _dist()
     if dist is None:
         return None
-    return dist.all_reduce(opt.flat_grad, async_op=True)
+    return ptu.all_reduce(opt.flat_grad, async_op=True)
 
 
 def _allreduce_finish(opt, work):
@@ -319,7 +319,7 @@ class MAPPOTrainer:
         stats = torch.stack([(adv * w).sum().double(), (adv.double() ** 2 * w).sum(), w.sum().double()])
         dist = _dist()
         if dist is not None:
-            dist.all_reduce(stats)
+            ptu.all_reduce(stats)
         mean = stats[0] / stats[2]
         var = (stats[1] / stats[2] - mean ** 2).clamp(min=0.0)
         return ((adv - mean.float()) / (torch.sqrt(var).float() + 1e-5))
@@ -417,7 +417,7 @@ class MAPPOTrainer:
         dist = _dist()
         if dist is not None:
             acc = acc.clone()
-            dist.all_reduce(acc)
+            ptu.all_reduce(acc)
             acc /= dist.get_world_size()
         return acc
 

@@ -255,8 +255,7 @@ class Learner:
         rew_acc, cov_max = stats           # reduced over the envs HERE, outside any captured graph
         stats = torch.stack([rew_acc.mean(), cov_max.double().mean()])
         if self.dist_on:
-            import torch.distributed as dist
-            dist.all_reduce(stats)
+            ptu.all_reduce(stats)
             stats /= self.world
         r, c = stats.tolist()
         return {"reward": r, "coverage_rate": c}

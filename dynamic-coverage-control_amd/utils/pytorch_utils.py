@@ -99,6 +99,44 @@ def dist_active():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_group())
 
 
+class _Done(object):
+    """Handle of a collective that has already completed (the host-staged gloo path below)."""
+
+    def wait(self):
+        return True
+
+
+def _stage_through_host(t):
+    """True when a collective on device tensor `t` is to be staged through the host by THIS code.
+    RCCL (backend "nccl", the product path: one process per GPU) reduces device buffers in place.  gloo has no device transport:
+    torch's ProcessGroupGloo moves a CUDA tensor through pinned staging buffers it allocates per call and copy streams of its own.
+    On the gloo test hook (several ranks sharing one GPU: DCC_DIST_BACKEND / DCC_BENCH_BACKEND = gloo) DCC_GLOO_VIA_HOST=1 makes
+    the copies plain `.cpu()` / `copy_` on the current stream instead (tools/world8_ab.py measures what that changes)."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend() == "gloo" and os.environ.get("DCC_GLOO_VIA_HOST", "0") == "1"
+
+
+def all_reduce(t, async_op=False):
+    """dist.all_reduce(t) (sum, in place).  async_op: returns a handle with .wait()."""
+    import torch.distributed as dist
+    if _stage_through_host(t):
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+        return _Done() if async_op else None
+    return dist.all_reduce(t, async_op=async_op)
+
+
+def broadcast(t, src=0):
+    import torch.distributed as dist
+    if _stage_through_host(t):
+        h = t.cpu()
+        dist.broadcast(h, src)
+        t.copy_(h)
+        return
+    dist.broadcast(t, src)
+
+
 def world_size():
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1

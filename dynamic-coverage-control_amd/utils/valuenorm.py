@@ -39,7 +39,7 @@ class ValueNorm(nn.Module):
         import utils.pytorch_utils as ptu
         if ptu.dist_active():
             both = torch.stack([batch_mean.reshape(-1), batch_sq_mean.reshape(-1)])
-            dist.all_reduce(both)
+            ptu.all_reduce(both)
             both /= dist.get_world_size()
             batch_mean, batch_sq_mean = both[0].reshape(batch_mean.shape), both[1].reshape(batch_sq_mean.shape)
         if self.per_element_update:
