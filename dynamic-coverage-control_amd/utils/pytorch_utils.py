@@ -109,11 +109,14 @@ class _Done(object):
 def _stage_through_host(t):
     """True when a collective on device tensor `t` is to be staged through the host by THIS code.
     RCCL (backend "nccl", the product path: one process per GPU) reduces device buffers in place.  gloo has no device transport:
-    torch's ProcessGroupGloo moves a CUDA tensor through pinned staging buffers it allocates per call and copy streams of its own.
-    On the gloo test hook (several ranks sharing one GPU: DCC_DIST_BACKEND / DCC_BENCH_BACKEND = gloo) DCC_GLOO_VIA_HOST=1 makes
-    the copies plain `.cpu()` / `copy_` on the current stream instead (tools/world8_ab.py measures what that changes)."""
+    torch's ProcessGroupGloo moves a CUDA tensor through pinned staging buffers it allocates per call and SDMA copies on streams
+    of its own.  With EIGHT processes sharing one GPU (the gloo test hook: DCC_DIST_BACKEND / DCC_BENCH_BACKEND = gloo) that path
+    makes a rank die with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION -- in whatever kernel is running, stock torch kernels included --
+    in 42 of 144 jobs; with the copies made here as plain `.cpu()` / `copy_` on the current stream 0 of 34, and 0 of 54 with
+    HSA_ENABLE_SDMA=0 (profiles/r05/world8_ab.txt).  So on gloo the tensors are staged here; DCC_GLOO_VIA_HOST=0 restores torch's
+    path (the A/B knob of tools/world8_ab.py)."""
     import torch.distributed as dist
-    return t.is_cuda and dist.get_backend() == "gloo" and os.environ.get("DCC_GLOO_VIA_HOST", "0") == "1"
+    return t.is_cuda and dist.get_backend() == "gloo" and os.environ.get("DCC_GLOO_VIA_HOST", "1") != "0"
 
 
 def all_reduce(t, async_op=False):
