@@ -51,6 +51,29 @@ class _LinearSplitK(torch.autograd.Function):
         return dx, dW
 
 
+class _SelectRows(torch.autograd.Function):
+    """x[idx] for UNIQUE row indices idx (a row mini-batch): the backward is a plain scatter into zeros (index_copy_) instead of
+    index_select's atomic index_add_."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = x.shape[0]
+        return x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        out = g.new_zeros((ctx.n,) + tuple(g.shape[1:]))
+        out.index_copy_(0, idx, g.contiguous())
+        return out, None
+
+
+def select_rows(x, idx):
+    """Rows `idx` (unique) of x [n, .], differentiable."""
+    return _SelectRows.apply(x, idx)
+
+
 def linear_w(x, W):
     """x [R, K] @ W^T for a weight tensor W [H, K] (split-K weight gradient for long batches on the GPU)."""
     if x.dim() == 2 and x.is_cuda and x.shape[0] >= 65536 and x.is_contiguous() and not torch.is_autocast_enabled():

@@ -240,7 +240,7 @@ def actor_trunk(base, layout, feats, head=None, row_sel=None):
     blk = base.mlp.fc1
     if isinstance(blk[1], nn.ReLU):   # one fused pass: the pre-activation never reaches memory (include/dcc_mlp.h)
         h = fused.actor_l1(head_f, g, stats if eps is not None else None, w_h, s_w, c, blk[2], eps, layout.D)
-        return _rest(base, h if row_sel is None else h.index_select(0, row_sel), head)
+        return _rest(base, h if row_sel is None else fused.select_rows(h, row_sel), head)
     z = F.linear(head_f.reshape(n * N, HD), w_h).view(n, N, -1) + g.unsqueeze(1)
     if eps is not None:
         mean = stats[..., 0]
@@ -249,7 +249,7 @@ def actor_trunk(base, layout, feats, head=None, row_sel=None):
     else:
         z = z + c
     z = z.reshape(n * N, -1)
-    return _rest(base, _tail(blk, z if row_sel is None else z.index_select(0, row_sel)), head)
+    return _rest(base, _tail(blk, z if row_sel is None else fused.select_rows(z, row_sel)), head)
 
 
 def critic_trunk(base, layout, feats, head=None):

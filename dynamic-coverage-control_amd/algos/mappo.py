@@ -397,9 +397,12 @@ class MAPPOTrainer:
         generator, which is what the reference draws from."""
         acc = torch.zeros(6, dtype=torch.float64, device=ptu.device)
         n_updates = 0
+        if getattr(buffer, "structured", False):       # the whole batch's state features: parameter-free, computed once per iteration
+            buffer.features_rows(0, buffer.episode_length)
         for _ in range(self.ppo_epoch):
             perm = self.minibatch_perms.pop(0) if getattr(self, "minibatch_perms", None) else None
-            for sample in buffer.feed_forward_generator(advantages, self.num_mini_batch, dedup_critic=self.dedup_critic, perm=perm):
+            for sample in buffer.feed_forward_generator(advantages, self.num_mini_batch, dedup_critic=self.dedup_critic, perm=perm,
+                                                        row_width=self.policy.actor.hidden_size):
                 vl, cgn, pl, ent, agn, imp = self.ppo_update(sample, update_actor)
                 acc += torch.stack([vl.detach().double(), pl.detach().double(), ent.detach().double(), agn.double(), cgn.double(),
                                     imp.detach().mean().double()])

@@ -181,6 +181,7 @@ class SharedReplayBuffer(object):
         self.rnn_states = z(T + 1, E, N, cfg.recurrent_N, cfg.algo_hidden_size if self.recurrent else 0)
         self.rnn_states_critic = torch.zeros_like(self.rnn_states)
         self.available_actions = None
+        self.minibatch_unique_pairs = False     # True: row mini-batches always work on the unique touched (step, env) pairs (tests)
         self.step = 0
 
     # ---- slots the env kernel writes into / the policy reads from ----------------------------------------
@@ -404,7 +405,8 @@ class SharedReplayBuffer(object):
                             self.returns.view(T + 1, E * N), self.advantages_raw.view(T, E * N))
 
     # ---- sampling -----------------------------------------------------------------------------------------------
-    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None, dedup_critic=False, perm=None):
+    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None, dedup_critic=False, perm=None,
+                               row_width=None):
         """shared_buffer.py:219-279.  Yields the reference's 12-tuple of [B, .] tensors (device).
         One mini-batch (the shipped setting): the whole batch in storage order, without the randperm gather (every loss is
         a mean over the batch, order-free).  More than one: the reference's mini-batches -- one permutation of the
@@ -432,7 +434,7 @@ class SharedReplayBuffer(object):
             mini_batch_size = batch_size // num_mini_batch
         perm = torch.randperm(batch_size) if perm is None else torch.as_tensor(perm).reshape(-1).long()
         for i in range(num_mini_batch):
-            yield self.minibatch_rows(advantages, perm[i * mini_batch_size:(i + 1) * mini_batch_size], dedup_critic)
+            yield self.minibatch_rows(advantages, perm[i * mini_batch_size:(i + 1) * mini_batch_size], dedup_critic, row_width)
 
     def features_of_pairs(self, pairs):
         """Policy-input features (dcc_obs_features) of the (step, env) states `pairs` (indices into the T*E flattening)."""
@@ -448,7 +450,7 @@ class SharedReplayBuffer(object):
         self._expand(g(self.state_pos), g(self.state_vel), g(self.state_energy), g(self.state_done), out)
         return out
 
-    def minibatch_rows(self, advantages, rows, dedup_critic=False):
+    def minibatch_rows(self, advantages, rows, dedup_critic=False, row_width=None):
         """The reference's mini-batch for the agent rows `rows` -- indices into the (t, e, n) flattening of the T*E*N rows,
         what `sampler` holds at shared_buffer.py:239-240 -- as its 12-tuple (:258-279).
         A row (t, e, n) needs agent n's observation of state (t, e) and the centralised observation of that state.  Neither is
@@ -458,6 +460,11 @@ class SharedReplayBuffer(object):
           * state-only:       the touched states are gathered (32N + 5M bytes each) and their rows regenerated
                               (dcc_obs_expand), then as above;
           * structured input: obs_batch = share_obs_batch = the features of the touched states (dcc_obs_features).
+        Which pairs are "touched": a mini-batch of at least half as many rows as there are pairs touches most of them (k mini-
+        batches of N-agent envs: 1 - (1 - 1/k)^N; 99.6 % at k = 2, N = 8), so ALL T*E pairs are used -- static shapes, no
+        torch.unique (a host sync + a sort per mini-batch), the per-iteration feature cache serves every mini-batch, and the
+        allocator sees the same sizes every time.  Smaller mini-batches (or a batch whose [rows, row_width] activation would pass
+        2^31 elements, see MAPPOTrainer.train) take the unique touched pairs.
         When a batch entry is per pair instead of per row the tuple gets a 13th element (row_sel, pair_sel): index vectors that
         pick each row's actor output out of the [pairs*N] outputs (None: obs_batch is per row already) and each row's value
         out of the [pairs] critic outputs (MAPPOTrainer._forward_losses applies them -- the row selection right after the
@@ -471,9 +478,13 @@ class SharedReplayBuffer(object):
         tail = (g(self.actions), g(self.value_preds[:-1]), g(self.returns[:-1]), g(self.masks[:-1]), g(self.active_masks[:-1]),
                 g(self.action_log_probs), g(adv), None)
         pair, agent = rows // N, rows % N
+        all_pairs = (rows.numel() * 2 >= T * E and B * int(row_width or 512) < 2 ** 31 and not self.minibatch_unique_pairs)
         if self.structured:
             if not dedup_critic:
                 raise NotImplementedError("structured input evaluates the centralised critic once per env (dedup_critic)")
+            if all_pairs:       # the whole batch's features (cached per iteration, shared by all epochs and mini-batches)
+                f = self.features_rows(0, T)
+                return (f, f, None, None) + tail + ((rows, pair),)
             pairs, inv = torch.unique(pair, return_inverse=True)
             f = self.features_of_pairs(pairs)
             return (f, f, None, None) + tail + ((inv * N + agent, inv),)
@@ -488,6 +499,8 @@ class SharedReplayBuffer(object):
         obs = self.obs[:-1].reshape(B, -1)[rows]
         so_env = self.share_obs_env[:-1].reshape(T * E, -1)
         if dedup_critic:
+            if all_pairs:       # the stored centralised rows as they are (a view: nothing gathered)
+                return (so_env, obs, None, None) + tail + ((None, pair),)
             pairs, inv = torch.unique(pair, return_inverse=True)
             return (so_env[pairs], obs, None, None) + tail + ((None, inv),)
         return (so_env[pair], obs, None, None) + tail

@@ -1423,9 +1423,9 @@ kernel_fn pick_spec(int n, int m) {
     if (n == 4 && m == 16) return dcc_env_kernel<1, ACT, FORCE, 4, 16>;
     if (n == 4 && m == 20) return dcc_env_kernel<1, ACT, FORCE, 4, 20>;
     if (n == 16 && m == 256) return dcc_env_kernel<4, ACT, FORCE, 16, 256>;
-    if constexpr (FORCE) {      // c5 (32,1024) runs with the pull force on (BASELINE configs[4]); force-off 32 x 1024 stays generic
-        if (n == 32 && m == 1024) return dcc_env_kernel<16, ACT, FORCE, 32, 1024>;
-    }
+    // (32, 1024) -- c5 -- deliberately has NO compile-time instantiation: measured in round 5, `<16, ACT, true, 32, 1024>` needs 256
+    // VGPRs + 16-22 spilled against the generic kernel's 226 / 0 and streams 4 % SLOWER at the 2048-env shard (0.652-0.664 vs
+    // 0.690-0.691 of the HBM peak, three interleaved runs each; profiles/r05/c5_spec_ab.txt)
     return nullptr;
 }
 

@@ -205,22 +205,25 @@ def test_buffer_gae_has_no_cpu_path():
         buf.compute_returns(torch.zeros(E, N, 1), ValueNorm(1))
 
 
+@pytest.mark.parametrize("k", [3, 12])
 @pytest.mark.parametrize("dedup", [False, True])
-def test_mini_batch_generator_partitions_the_rollout(dedup):
+def test_mini_batch_generator_partitions_the_rollout(dedup, k):
     """num_mini_batch > 1 follows the reference's feed_forward_generator (shared_buffer.py:239-279): one
     permutation of the T*E*N agent rows drawn with torch.randperm on the CPU generator, cut into num_mini_batch row sets;
     every field is the gather of those rows, the critic rows stay aligned with the agent rows."""
-    cfg = make_cfg(num_mini_batch=3, dedup_critic=dedup)
+    cfg = make_cfg(num_mini_batch=k, dedup_critic=dedup)
     buf = _filled_buffer(cfg)
     B = T * E * N
+    # k = 3: 64-row mini-batches over 48 (step, env) pairs touch most pairs -> every pair is handed out (static shapes);
+    # k = 12: 16 rows -> the unique touched pairs
     adv = torch.arange(B, dtype=torch.float32).view(T, E, N, 1)     # row id as the advantage
     seen = []
     torch.manual_seed(0)
     want = torch.randperm(B)                                          # what the reference's generator would draw after this seed
     torch.manual_seed(0)
-    for i, s in enumerate(buf.feed_forward_generator(adv, 3, dedup_critic=dedup)):
+    for i, s in enumerate(buf.feed_forward_generator(adv, k, dedup_critic=dedup)):
         share, obs, acts, ids = s[0], s[1], s[4], s[10].view(-1).long()
-        assert torch.equal(ids, want[i * (B // 3):(i + 1) * (B // 3)])                 # the reference's row sets, in its order
+        assert torch.equal(ids, want[i * (B // k):(i + 1) * (B // k)])                 # the reference's row sets, in its order
         np.testing.assert_array_equal(obs.numpy(), Z["buf_obs"][:-1].reshape(B, D)[ids.numpy()])
         np.testing.assert_array_equal(acts.numpy(), Z["buf_actions"].reshape(B, A)[ids.numpy()])
         np.testing.assert_array_equal(s[5].numpy(), buf.value_preds[:-1].reshape(B, 1)[ids].numpy())
@@ -228,14 +231,14 @@ def test_mini_batch_generator_partitions_the_rollout(dedup):
         so_rows = Z["buf_obs"][:-1].reshape(T * E, S)[(ids // N).numpy()]            # the centralised row of each agent row
         if dedup:                                                                      # one row per touched (step, env) pair + selectors
             row_sel, pair_sel = s[12]
-            assert row_sel is None and share.shape[0] == ids.div(N, rounding_mode="floor").unique().numel()
+            assert row_sel is None and share.shape[0] == (T * E if k == 3 else ids.div(N, rounding_mode="floor").unique().numel())
             np.testing.assert_array_equal(share[pair_sel].numpy(), so_rows)
         else:                                                                          # the reference's 12-tuple exactly
             assert len(s) == 12
             np.testing.assert_array_equal(share.numpy(), so_rows)
         seen.append(ids)
     allids = torch.cat(seen)
-    assert allids.numel() == (B // 3) * 3 and allids.unique().numel() == allids.numel()
+    assert allids.numel() == (B // k) * k and allids.unique().numel() == allids.numel()
 
 
 def test_train_with_two_mini_batches_runs():
