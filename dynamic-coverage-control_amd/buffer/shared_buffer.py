@@ -410,8 +410,7 @@ class SharedReplayBuffer(object):
         """shared_buffer.py:219-279.  Yields the reference's 12-tuple of [B, .] tensors (device).
         One mini-batch (the shipped setting): the whole batch in storage order, without the randperm gather (every loss is
         a mean over the batch, order-free).  More than one: the reference's mini-batches -- one permutation of the
-        T*E*N agent rows (torch.randperm on the CPU generator, like the reference draws it, so the same seed selects the
-        same rows; `perm` injects one), cut into num_mini_batch row sets of batch_size // num_mini_batch rows
+        T*E*N agent rows (`perm` injects one), cut into num_mini_batch row sets of batch_size // num_mini_batch rows
         (`minibatch_rows`).  Works on every storage mode: row storage gathers rows, a state-only buffer gathers env states.
         dedup_critic: `share_obs_batch` carries ONE row per (step, env) pair the mini-batch touches."""
         T, E, N = self.episode_length, self.n_rollout_threads, self.num_agents
@@ -432,7 +431,14 @@ class SharedReplayBuffer(object):
                 raise ValueError("PPO requires n_rollout_threads (%d) * max_ep_len (%d) * num_agents (%d) >= num_mini_batch (%d)"
                                  % (E, T, N, num_mini_batch))
             mini_batch_size = batch_size // num_mini_batch
-        perm = torch.randperm(batch_size) if perm is None else torch.as_tensor(perm).reshape(-1).long()
+        if perm is None:
+            # On the CPU the permutation comes from torch's CPU generator exactly like the reference's (the same seed selects the
+            # same rows: tests/test_mappo_env_golden.py).  On the GPU it is drawn on the device: a CPU randperm of the c3 batch
+            # (4.9 M rows) costs ~60 ms per epoch + a 39 MB upload -- more than the epoch's kernels -- and the reference's random
+            # stream cannot be followed on the device anyway (the action noise is drawn there too).
+            perm = torch.randperm(batch_size, device=self.device) if self.device.type == "cuda" else torch.randperm(batch_size)
+        else:
+            perm = torch.as_tensor(perm).reshape(-1).long()
         for i in range(num_mini_batch):
             yield self.minibatch_rows(advantages, perm[i * mini_batch_size:(i + 1) * mini_batch_size], dedup_critic, row_width)
 
