@@ -107,6 +107,10 @@ def _replay(fixture, storage, gpu, capsys):
     ref_cfg = json.loads(str(Z["cfg_json"]))
     E, N, M, T, H, n_iters, n_roll = [int(x) for x in Z["dims"]]
     assert (N, M) == ((8, 64) if fixture.endswith("n8m64") else (4, 20)) and ref_cfg["num_agents"] == N
+    # Tolerances sit <= 10x above what the runs achieve (profiles/r05/learner_replay_errors.txt).  One env
+    # means a 160-row batch: its Adam updates amplify fp32 noise (achieved 6.0e-3 of max|delta| per iteration, 1.1e-5 in the later
+    # rollouts); two envs achieve 1.6e-4 and 3.7e-6.
+    DELTA, LATER = (1e-2, 5.0) if E == 1 else (1.5e-3, 3.0)
     over = dict(use_hip_graph=False)          # the injected noise replaces the in-graph philox stream
     if storage == "rows":
         over.update(structured_input=False, compact_obs=False)
@@ -156,7 +160,7 @@ def _replay(fixture, storage, gpu, capsys):
         # Iteration 1 runs on the fixture's own parameters: pure forward / env / GAE parity, <= 1e-5 relative (2e-5 for what comes
         # straight out of the fp32 networks).  From iteration 2 on the parameters are this run's own (updates within 1 % of the
         # reference's, see rl_update below), and that drift feeds back through actions -> positions -> rewards: 5x the window.
-        w = 1.0 if st["iter"] == 1 else 5.0
+        w = 1.0 if st["iter"] == 1 else LATER
         tag = "%s@%d" % ("" if st["iter"] == 1 else "_later", k)
         trk.close("actions" + tag, g("actions"), Z[pre + "actions"], 2e-5 * w)
         trk.close("action_log_probs" + tag, g("action_log_probs"), Z[pre + "action_log_probs"], 2e-5 * w)
@@ -192,11 +196,11 @@ def _replay(fixture, storage, gpu, capsys):
                 if scale == 0.0:            # lr = 0 (last iteration of the linear schedule): nothing may move
                     assert float(np.abs(d_got).max()) == 0.0, "%s%s moved on the lr = 0 iteration" % (rtag, name)
                 else:
-                    trk.close("delta_%s%s@%d" % (rtag, name, i), d_got, d_ref, 1e-2, scale=scale)
+                    trk.close("delta_%s%s@%d" % (rtag, name, i), d_got, d_ref, DELTA, scale=scale)
                 # ... and the drift of the parameter itself since iteration 0, against the distance the reference has moved
                 c_ref = Z[pre + rtag + name].astype(np.float64) - init[tag][name].astype(np.float64)
                 trk.close("drift_%s%s@%d" % (rtag, name, i), v.double().cpu().numpy() - init[tag][name].astype(np.float64), c_ref,
-                          1e-2, scale=float(np.abs(c_ref).max()))
+                          DELTA, scale=float(np.abs(c_ref).max()))
                 prev[tag][name] = v.clone()
                 prev["r" + tag][name] = Z[pre + rtag + name]
         return info

@@ -146,7 +146,7 @@ def test_recurrent_train_reproduces_the_reference_update(mode, dev):
             np.testing.assert_allclose(_np(v), Z["%s%s2/%s" % (pre, name, k)], rtol=2e-4, atol=2e-6, err_msg=k)
         # ... and as UPDATES: max |d_got - d_ref| <= tol * max |d_ref| per tensor (achieved: run summary)
         check_param_deltas(net, {k: Z["%s%s/%s" % (pre, name, k)] for k in sd}, {k: Z["%s%s2/%s" % (pre, name, k)] for k in sd},
-                           1e-2 if dev == "cuda" else 5e-4, "mappo_rnn %s %s %s" % (mode, dev, name))
+                           1e-3 if dev == "cuda" else 3e-4, "mappo_rnn %s %s %s" % (mode, dev, name))      # achieved: 1.12e-4 / 4.5e-5
     assert "rnn.rnn.weight_hh_l0" in pol.actor.state_dict() and "rnn.norm.weight" in pol.critic.state_dict()
 
 
