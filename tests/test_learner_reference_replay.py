@@ -39,7 +39,7 @@ def _shipped_cfg(ref_cfg, **over):
     for f in ("config/env_config/dcc.yaml", "config/algo_config/mappo.yaml", "config/expt.yaml"):
         cfg.update(yaml.safe_load(open(os.path.join(PKG, f))))
     for k in ("n_rollout_threads", "max_ep_len", "algo_hidden_size", "n_iters", "eval_interval", "save_model", "log_wandb",
-              "num_agents", "num_pois"):
+              "num_agents", "num_pois", "use_recurrent_policy"):
         cfg[k] = ref_cfg[k]
     for k, v in ref_cfg.items():
         if k in ("save_gifs",):
@@ -79,15 +79,17 @@ def _set_params(module, Z, prefix):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("storage", ["shipped", "rows"])
-@pytest.mark.parametrize("fixture", ["e1", "e2", "e2_n8m64"])
+@pytest.mark.parametrize("fixture", ["e1", "e2", "e2_n8m64", "e2_rnn"])
 def test_learner_replays_the_reference_learner(fixture, storage, capsys):
     """e1 / e2: the shipped 4 UAV x 20 PoI task on 1 env (DummyVecEnv in the reference) / 2 envs (SubprocVecEnv); e2_n8m64: the
-    BASELINE c2 / c3 task size, 8 UAV x 64 PoI, through the size-generalised scenario (tools/gen_golden_learner.py)."""
+    BASELINE c2 / c3 task size, 8 UAV x 64 PoI, through the size-generalised scenario (tools/gen_golden_learner.py); e2_rnn:
+    `use_recurrent_policy: true` -- the orchestrator's GRU branch (states through collect / insert, zeroed on episode ends,
+    carried over by after_update: learner.py:231-265) and the recurrent generator in the update; on the shipped YAMLs the Learner
+    falls back to row storage by itself for it."""
     _replay(fixture, storage, True, capsys)
 
 
-@pytest.mark.parametrize("storage", ["rows", "state-only"])
-@pytest.mark.parametrize("fixture", ["e1", "e2", "e2_n8m64"])
+@pytest.mark.parametrize("fixture,storage", [(f, s) for f in ("e1", "e2", "e2_n8m64") for s in ("rows", "state-only")] + [("e2_rnn", "rows")])
 def test_orchestrator_replays_the_reference_learner_on_the_cpu(fixture, storage, capsys, oracle_mod):
     """The same replay without a GPU: the package's Learner / vec-env / buffer / trainer on torch CPU tensors, with the `_cpu` twins
     of the C-ABI standing in for the two device entry points (tests/_cpu_twin_backend.py).  Pins the host-side orchestration --
@@ -119,7 +121,11 @@ def _replay(fixture, storage, gpu, capsys):
     ptu.set_gpu_mode(gpu, 0)
     from learner import Learner
     lr = Learner(_shipped_cfg(ref_cfg, **over))
-    assert lr.rl_buffer.compact == (storage != "rows") and lr.rl_buffer.structured == (storage == "shipped")
+    rnn = bool(ref_cfg["use_recurrent_policy"])
+    if rnn:       # recurrent policies read rows step by step: the Learner switches the shipped state-only storage off on its own
+        assert lr.recurrent and not lr.rl_buffer.compact and not lr.rl_buffer.structured
+    else:
+        assert lr.rl_buffer.compact == (storage != "rows") and lr.rl_buffer.structured == (storage == "shipped")
     _set_params(lr.policy.actor, Z, "init/actor/")
     _set_params(lr.policy.critic, Z, "init/critic/")
     invalidate_folded_weights(lr.policy.actor, lr.policy.critic)
@@ -167,6 +173,10 @@ def _replay(fixture, storage, gpu, capsys):
         trk.close("rewards" + tag, g("rewards"), Z[pre + "rewards"], 1e-5 * w)
         trk.close("value_preds" + tag, g("value_preds"), Z[pre + "value_preds"], 2e-5 * w)
         trk.close("returns" + tag, g("returns"), Z[pre + "returns"], 1e-5 * w)
+        if rnn:     # GRU states of every slot, zeros where an episode ended, slot 0 = what after_update carried over
+            trk.close("rnn_states" + tag, g("rnn_states"), Z[pre + "rnn_states"], 2e-5 * w, scale=1.0)
+            trk.close("rnn_states_critic" + tag, g("rnn_states_critic"), Z[pre + "rnn_states_critic"], 2e-5 * w, scale=1.0)
+            assert not g("rnn_states")[1:][Z[pre + "masks"][1:, :, :, 0] == 0].any()
         if pre + "obs" in Z.files:      # (the 8 x 64 fixture stores the rows of its first rollout only)
             obs = torch.stack([torch.as_tensor(r_buffer.obs[t]) for t in range(T + 1)]).cpu().numpy()   # rows / regenerated from state
             trk.close("obs" + tag, obs, Z[pre + "obs"], 2e-5 * w, scale=1.0)

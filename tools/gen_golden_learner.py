@@ -6,6 +6,7 @@ eval_interval).  Container-only (needs /root/reference); the outputs are data.  
     python tools/gen_golden_learner.py 1      # n_rollout_threads 1 -> DummyVecEnv        (envs/wrappers.py:204-236)
     python tools/gen_golden_learner.py 2      # n_rollout_threads 2 -> SubprocVecEnv      (envs/wrappers.py:133-202)
     python tools/gen_golden_learner.py 2 8 64 # the BASELINE c2 / c3 task size (8 UAV x 64 PoI) -> learner_ref_e2_n8m64.npz
+    python tools/gen_golden_learner.py 2 rnn  # use_recurrent_policy: true (GRU actor / critic)  -> learner_ref_e2_rnn.npz
 
 The third form needs the size-generalised scenario: the shipped one hard-codes 4 x 20 in make_world (coverage.py:40-41), so
 `scenarios.load` is pointed at tools/ref_harness.sized_scenario_class (ONLY make_world replaced) before the envs are built;
@@ -68,7 +69,7 @@ def vn_np(vn, prefix, out):
     out[prefix + "vn_debias"] = vn.debiasing_term.numpy().copy()
 
 
-def main(E, N=None, M=None):
+def main(E, N=None, M=None, rnn=False):
     _stub_modules()
     sized = N is not None
     os.chdir(REF)                         # the reference resolves ./config/... and ./envs/... relative to its own directory
@@ -87,6 +88,8 @@ def main(E, N=None, M=None):
     cfg.algo_hidden_size = 32
     cfg.n_iters = 4
     cfg.eval_interval = 2
+    if rnn:        # the reference's recurrent branch of the orchestrator: GRU states in collect / insert (zeroed on episode ends,
+        cfg.use_recurrent_policy = True      # learner.py:258-265), carried over by after_update, recurrent_generator in the update
     if sized:
         cfg.num_agents, cfg.num_pois = N, M
         from argparse import Namespace as _NS
@@ -138,6 +141,8 @@ def main(E, N=None, M=None):
                     pre + "action_log_probs": r_buffer.action_log_probs.copy(), pre + "rewards": r_buffer.rewards.copy(),
                     pre + "masks": r_buffer.masks.copy(), pre + "value_preds": r_buffer.value_preds.copy(),
                     pre + "returns": r_buffer.returns.copy(),
+                    **({pre + "rnn_states": r_buffer.rnn_states.copy(), pre + "rnn_states_critic": r_buffer.rnn_states_critic.copy()}
+                       if rnn else {}),
                     pre + "info_reward": np.array(float(info["reward"])),
                     pre + "info_coverage_rate": np.array(float(info["coverage_rate"]))})
         if not sized or state["k"] == 0:
@@ -162,7 +167,7 @@ def main(E, N=None, M=None):
     learner.train()
 
     out["dims"] = np.array([E, N, learner.cfg.num_pois, T, learner.cfg.algo_hidden_size, learner.cfg.n_iters, state["k"]])
-    path = os.path.join(HERE, "..", "tests", "golden", "learner_ref_e%d%s.npz" % (E, "_n%dm%d" % (N, M) if sized else ""))
+    path = os.path.join(HERE, "..", "tests", "golden", "learner_ref_e%d%s%s.npz" % (E, "_n%dm%d" % (N, M) if sized else "", "_rnn" if rnn else ""))
     np.savez_compressed(path, **out)
     ends = [int((out["r%d/masks" % k][1:, :, 0, 0] == 0).sum()) for k in range(state["k"])]
     print("wrote", os.path.normpath(path), os.path.getsize(path) // 1024, "KB; rollouts:", state["k"], "kinds:",
@@ -172,4 +177,5 @@ def main(E, N=None, M=None):
 
 
 if __name__ == "__main__":
-    main(*[int(v) for v in sys.argv[1:4]] or [2])
+    argv = [a for a in sys.argv[1:] if a != "rnn"]
+    main(*([int(v) for v in argv[:3]] or [2]), rnn="rnn" in sys.argv[1:])
