@@ -20,7 +20,8 @@ cfg = {}
 for f in ("config/env_config/dcc.yaml", "config/algo_config/mappo.yaml", "config/expt.yaml"):
     cfg.update(yaml.safe_load(open(os.path.join(PKG, f))))
 cfg.update(n_rollout_threads=64, n_eval_rollout_threads=0, num_agents=4, num_pois=20, max_ep_len=25, n_iters=3, ppo_epoch=3,
-           algo_hidden_size=64, save_model=False, seed=3)
+           algo_hidden_size=64, save_model=False, seed=3,
+           num_mini_batch=int(os.environ.get("DCC_TEST_MINI_BATCH", "1")))     # > 1: every rank permutes its own rows (row mini-batches)
 from learner import Learner  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

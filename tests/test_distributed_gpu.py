@@ -11,11 +11,13 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_two_rank_gpu_training_keeps_replicas_identical():
+@pytest.mark.parametrize("mini_batches", [1, 2])
+def test_two_rank_gpu_training_keeps_replicas_identical(mini_batches):
+    """mini_batches = 2: the reference's row mini-batches on the shipped state-only storage, each rank over its own env shard."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "tests", "_dist_gpu_worker.py")]
+           "--master-port", str(29540 + mini_batches), os.path.join(ROOT, "tests", "_dist_gpu_worker.py")]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, DCC_DIST_BACKEND="gloo"))
+                       env=dict(os.environ, DCC_DIST_BACKEND="gloo", DCC_TEST_MINI_BATCH=str(mini_batches)))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "DIST_GPU_OK" in r.stdout
 
