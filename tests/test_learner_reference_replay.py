@@ -111,8 +111,9 @@ def _replay(fixture, storage, gpu, capsys):
     assert (N, M) == ((8, 64) if fixture.endswith("n8m64") else (4, 20)) and ref_cfg["num_agents"] == N
     # Tolerances sit <= 10x above what the runs achieve (profiles/r05/learner_replay_errors.txt).  One env
     # means a 160-row batch: its Adam updates amplify fp32 noise (achieved 6.0e-3 of max|delta| per iteration, 1.1e-5 in the later
-    # rollouts); two envs achieve 1.6e-4 and 3.7e-6.
-    DELTA, LATER = (1e-2, 5.0) if E == 1 else (1.5e-3, 3.0)
+    # rollouts); two envs achieve 1.6e-4 and 3.7e-6; the GRU policies on the GPU 2.2e-3 (CPU 5.6e-5: the recurrent update's
+    # chunked BPTT sums in another order there) and 4.1e-7.
+    DELTA, LATER = (1e-2, 5.0) if (E == 1 or fixture.endswith("rnn")) else (1.5e-3, 3.0)
     over = dict(use_hip_graph=False)          # the injected noise replaces the in-graph philox stream
     if storage == "rows":
         over.update(structured_input=False, compact_obs=False)
