@@ -397,7 +397,21 @@ class MAPPOTrainer:
         generator, which is what the reference draws from."""
         acc = torch.zeros(6, dtype=torch.float64, device=ptu.device)
         n_updates = 0
-        if getattr(buffer, "structured", False):       # the whole batch's state features: parameter-free, computed once per iteration
+        # No activation of a mini-batch may reach 2^31 elements (see train(): a torch kernel of the backward pass faults beyond
+        # that on this stack).  The full-batch path splits the batch into chunks for that; a mini-batch IS the unit the user
+        # asked for, so an oversized one is refused with the way out instead of being split behind the user's back.
+        T, E, N = buffer.episode_length, buffer.n_rollout_threads, buffer.num_agents
+        mb_rows = T * E * N // self.num_mini_batch
+        H = self.policy.actor.hidden_size
+        structured = getattr(buffer, "structured", False)
+        # structured input evaluates the first block for every agent of every touched (step, env) state (up to all of them)
+        widest = (min(T * E, mb_rows) * N * H) if structured else mb_rows * max(H, buffer.obs_dim)
+        if widest >= 2 ** 31:
+            need = -(-widest // (2 ** 31 - 1))
+            raise ValueError("num_mini_batch = %d leaves activations of %.2e elements per mini-batch (limit 2^31 on this stack): use "
+                             "num_mini_batch >= %d%s" % (self.num_mini_batch, widest, self.num_mini_batch * need,
+                                                        " (more than %d, so that a mini-batch touches fewer env states)" % (2 * N) if structured else ""))
+        if structured:       # the whole batch's state features: parameter-free, computed once per iteration
             buffer.features_rows(0, buffer.episode_length)
         for _ in range(self.ppo_epoch):
             perm = self.minibatch_perms.pop(0) if getattr(self, "minibatch_perms", None) else None
