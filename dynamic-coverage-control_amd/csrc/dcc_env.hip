@@ -103,10 +103,22 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave-wide float64 sum on the VALU (DPP moves of the two 32-bit halves: 4 steps leave every 16-lane row with its row sum,
+// the 4 row sums are combined through readlane) instead of 6 dependent ds_bpermute (LDS) round trips per reduction.
+// Deterministic; used by the env step's reward (latency chain of small batches) and by the feature producer (a chain of
+// 2N + 2 such reductions per state, purely latency-bound: 17 us per 4096 states with the ds_bpermute form).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_f64_dpp(double v) {
+    v += dpp_mov_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);   // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);   // row_mirror
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
 __device__ __forceinline__ double wave_min_f64(double v) {
@@ -509,7 +521,7 @@ __device__ __forceinline__ void env_physics_step(const KParams& p, const int env
         double smin = 1.7976931348623157e308, sprev = 1.7976931348623157e308;
 #pragma unroll UNR_F
         for (int i = 0; i < N; ++i) {
-            const double2 xa = apos_out[i];
+            const double2 xa = apos_out[i];   // (LDS broadcast read; fetching x_i with v_readlane from its owner lane is no faster, r05 A/B)
             const double dx = pj.x - xa.x, dy = pj.y - xa.y;
             const double s = __builtin_fma(dy, dy, dx * dx);
             cnt += (s <= p.sq_cover) ? 1 : 0;  // ||p_j - x_i|| <= r_cover (CW:164-165)
@@ -549,7 +561,10 @@ __device__ __forceinline__ void env_physics_step(const KParams& p, const int env
     }
     const bool any_oob = __ballot(oob) != 0ULL;
     const bool all_done = (n_done == M);
-    double base = wave_sum_f64(part);
+    // VALU-only (DPP) wave sum: the ds_bpermute form is 6 dependent LDS round trips, 0.2 us of the ~2 us step chain that bounds
+    // small batches (512 envs: 2.02 -> 1.81 us per step, profiles/r05/ab_small_batch_chain.txt); another summation order, equally
+    // far from the reference's sequential `rew -= min(dists)` loop (rewards are compared at 1e-12)
+    double base = wave_sum_f64_dpp(part);
     if (all_done) base += p.rew_done;
     // EN:106-108 sum over the N per-agent rewards; `just` bonus is paid once (SC:87-89)
     const double R = (double)N * base + p.rew_cover * (double)n_just;
@@ -825,24 +840,6 @@ struct FeatParams {
     int n, N, M; float m_energy;
     int stage;                  // 1: the N*HD head values of a state are assembled in LDS and stored as float4 runs
 };
-
-// Wave-wide float64 sum on the VALU (DPP moves of the two 32-bit halves: 4 steps leave every 16-lane row with its row sum,
-// the 4 row sums are combined through readlane) instead of 6 dependent ds_bpermute round trips per reduction: the feature
-// kernel is a chain of 2N + 2 such reductions per state and purely latency-bound (17 us per 4096 states before).
-// Deterministic, but a different summation order than wave_sum_f64 (which the env step keeps for its reward).
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum_f64_dpp(double v) {
-    v += dpp_mov_f64<0xB1>(v);    // quad_perm [1,0,3,2]
-    v += dpp_mov_f64<0x4E>(v);    // quad_perm [2,3,0,1]
-    v += dpp_mov_f64<0x141>(v);   // row_half_mirror
-    v += dpp_mov_f64<0x140>(v);   // row_mirror
-    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
-}
 
 // The features of ONE state held in a wave's registers: lane i < N has UAV i (mp, mv), lane l has PoIs {l, l + 64, ...}
 // (coordinates qx / qy, energy en, done bit t of dmask).  The PoI coordinates / energies / done flags are re-used by every
