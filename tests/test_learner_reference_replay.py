@@ -39,7 +39,7 @@ def _shipped_cfg(ref_cfg, **over):
     for f in ("config/env_config/dcc.yaml", "config/algo_config/mappo.yaml", "config/expt.yaml"):
         cfg.update(yaml.safe_load(open(os.path.join(PKG, f))))
     for k in ("n_rollout_threads", "max_ep_len", "algo_hidden_size", "n_iters", "eval_interval", "save_model", "log_wandb",
-              "num_agents", "num_pois", "use_recurrent_policy"):
+              "num_agents", "num_pois", "use_recurrent_policy", "num_mini_batch"):
         cfg[k] = ref_cfg[k]
     for k, v in ref_cfg.items():
         if k in ("save_gifs",):
@@ -79,17 +79,18 @@ def _set_params(module, Z, prefix):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("storage", ["shipped", "rows"])
-@pytest.mark.parametrize("fixture", ["e1", "e2", "e2_n8m64", "e2_rnn"])
+@pytest.mark.parametrize("fixture", ["e1", "e2", "e2_n8m64", "e2_rnn", "e2_mb2"])
 def test_learner_replays_the_reference_learner(fixture, storage, capsys):
     """e1 / e2: the shipped 4 UAV x 20 PoI task on 1 env (DummyVecEnv in the reference) / 2 envs (SubprocVecEnv); e2_n8m64: the
     BASELINE c2 / c3 task size, 8 UAV x 64 PoI, through the size-generalised scenario (tools/gen_golden_learner.py); e2_rnn:
     `use_recurrent_policy: true` -- the orchestrator's GRU branch (states through collect / insert, zeroed on episode ends,
     carried over by after_update: learner.py:231-265) and the recurrent generator in the update; on the shipped YAMLs the Learner
-    falls back to row storage by itself for it."""
+    falls back to row storage by itself for it; e2_mb2: `num_mini_batch: 2` -- 15 epochs x 2 row mini-batches per iteration, the
+    reference's permutations injected (on the shipped state-only storage this is SURVEY.md 8f row 4 end to end)."""
     _replay(fixture, storage, True, capsys)
 
 
-@pytest.mark.parametrize("fixture,storage", [(f, s) for f in ("e1", "e2", "e2_n8m64") for s in ("rows", "state-only")] + [("e2_rnn", "rows")])
+@pytest.mark.parametrize("fixture,storage", [(f, s) for f in ("e1", "e2", "e2_n8m64", "e2_mb2") for s in ("rows", "state-only")] + [("e2_rnn", "rows")])
 def test_orchestrator_replays_the_reference_learner_on_the_cpu(fixture, storage, capsys, oracle_mod):
     """The same replay without a GPU: the package's Learner / vec-env / buffer / trainer on torch CPU tensors, with the `_cpu` twins
     of the C-ABI standing in for the two device entry points (tests/_cpu_twin_backend.py).  Pins the host-side orchestration --
@@ -187,7 +188,11 @@ def _replay(fixture, storage, gpu, capsys):
         return info
 
     def rl_update():
+        i = st["iter"] + 0
+        if "i%d/perms" % (st["iter"]) in Z.files:      # the row permutations the reference's generator drew in this iteration
+            lr.trainer.minibatch_perms = [torch.from_numpy(p) for p in Z["i%d/perms" % st["iter"]]]
         info = orig_update()
+        assert not getattr(lr.trainer, "minibatch_perms", None)          # one permutation per epoch, all consumed
         i = st["iter"]
         pre = "i%d/" % i
         for key in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio"):

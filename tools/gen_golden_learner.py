@@ -7,6 +7,7 @@ eval_interval).  Container-only (needs /root/reference); the outputs are data.  
     python tools/gen_golden_learner.py 2      # n_rollout_threads 2 -> SubprocVecEnv      (envs/wrappers.py:133-202)
     python tools/gen_golden_learner.py 2 8 64 # the BASELINE c2 / c3 task size (8 UAV x 64 PoI) -> learner_ref_e2_n8m64.npz
     python tools/gen_golden_learner.py 2 rnn  # use_recurrent_policy: true (GRU actor / critic)  -> learner_ref_e2_rnn.npz
+    python tools/gen_golden_learner.py 2 mb2  # num_mini_batch: 2 (row mini-batches in every epoch) -> learner_ref_e2_mb2.npz
 
 The third form needs the size-generalised scenario: the shipped one hard-codes 4 x 20 in make_world (coverage.py:40-41), so
 `scenarios.load` is pointed at tools/ref_harness.sized_scenario_class (ONLY make_world replaced) before the envs are built;
@@ -69,7 +70,7 @@ def vn_np(vn, prefix, out):
     out[prefix + "vn_debias"] = vn.debiasing_term.numpy().copy()
 
 
-def main(E, N=None, M=None, rnn=False):
+def main(E, N=None, M=None, rnn=False, mb=1):
     _stub_modules()
     sized = N is not None
     os.chdir(REF)                         # the reference resolves ./config/... and ./envs/... relative to its own directory
@@ -88,6 +89,8 @@ def main(E, N=None, M=None, rnn=False):
     cfg.algo_hidden_size = 32
     cfg.n_iters = 4
     cfg.eval_interval = 2
+    if mb > 1:     # the reference's mini-batch loop (mappo.py:203-213 over shared_buffer.py:239-279); the permutations it draws with
+        cfg.num_mini_batch = mb              # torch.randperm are recorded (i<i>/perms [ppo_epoch, T*E*N])
     if rnn:        # the reference's recurrent branch of the orchestrator: GRU states in collect / insert (zeroed on episode ends,
         cfg.use_recurrent_policy = True      # learner.py:258-265), carried over by after_update, recurrent_generator in the update
     if sized:
@@ -152,8 +155,21 @@ def main(E, N=None, M=None, rnn=False):
         return info
 
     def rl_update():
-        info = orig_update()
+        perms, randperm = [], torch.randperm
+
+        def recording_randperm(*a, **k):     # torch's function, not the reference's
+            p = randperm(*a, **k)
+            perms.append(p.numpy().copy())
+            return p
+
+        torch.randperm = recording_randperm
+        try:
+            info = orig_update()
+        finally:
+            torch.randperm = randperm
         pre = "i%d/" % state["iter"]
+        if mb > 1:
+            out[pre + "perms"] = np.stack(perms).astype(np.int64)
         for k, v in info.items():
             out[pre + "info_" + k] = np.array(float(v))
         vn_np(learner.trainer.value_normalizer, pre, out)
@@ -167,7 +183,8 @@ def main(E, N=None, M=None, rnn=False):
     learner.train()
 
     out["dims"] = np.array([E, N, learner.cfg.num_pois, T, learner.cfg.algo_hidden_size, learner.cfg.n_iters, state["k"]])
-    path = os.path.join(HERE, "..", "tests", "golden", "learner_ref_e%d%s%s.npz" % (E, "_n%dm%d" % (N, M) if sized else "", "_rnn" if rnn else ""))
+    path = os.path.join(HERE, "..", "tests", "golden", "learner_ref_e%d%s%s%s.npz" % (E, "_n%dm%d" % (N, M) if sized else "", "_rnn" if rnn else "",
+                                                                                     "_mb%d" % mb if mb > 1 else ""))
     np.savez_compressed(path, **out)
     ends = [int((out["r%d/masks" % k][1:, :, 0, 0] == 0).sum()) for k in range(state["k"])]
     print("wrote", os.path.normpath(path), os.path.getsize(path) // 1024, "KB; rollouts:", state["k"], "kinds:",
@@ -177,5 +194,6 @@ def main(E, N=None, M=None, rnn=False):
 
 
 if __name__ == "__main__":
-    argv = [a for a in sys.argv[1:] if a != "rnn"]
-    main(*([int(v) for v in argv[:3]] or [2]), rnn="rnn" in sys.argv[1:])
+    flags = [a for a in sys.argv[1:] if a == "rnn" or a.startswith("mb")]
+    argv = [a for a in sys.argv[1:] if a not in flags]
+    main(*([int(v) for v in argv[:3]] or [2]), rnn="rnn" in flags, mb=max([int(a[2:]) for a in flags if a.startswith("mb")] or [1]))
