@@ -1,7 +1,8 @@
 """Generate tests/golden/mappo_env_small.npz: the REFERENCE MAPPO update (algos.mappo / buffer.shared_buffer / utils.valuenorm
 imported from /root/reference/uav_dcc_control) on a rollout of the REFERENCE env (tools/ref_harness.py), i.e. with real
 observation rows -- the fixture the structured-input path (first layers from env-state features) is checked against directly.
-Container-only; the outputs are data.  Re-run: python tools/gen_golden_mappo_env.py [small|n8m64]
+Container-only; the outputs are data.  Re-run: python tools/gen_golden_mappo_env.py [small|n8m64|n12m24|small_mb2|n8m64_mb3]
+(`*_mb<k>`: the same rollouts with num_mini_batch = k -- the reference's row mini-batches; the permutations it drew are stored)
 Second case `n8m64` (tests/golden/mappo_env_n8m64.npz): the BASELINE c2/c3 shape, 8 UAV x 64 PoI, E=2, T=31, hidden 32.
 Third case `n12m24`: 12 UAVs (more than 8: the learner's first block forms head . Wh^T with a library GEMM), 24 PoI, E=2, T=20.
 
