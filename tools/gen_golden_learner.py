@@ -11,9 +11,8 @@ eval_interval).  Container-only (needs /root/reference); the outputs are data.  
 
 The third form needs the size-generalised scenario: the shipped one hard-codes 4 x 20 in make_world (coverage.py:40-41), so
 `scenarios.load` is pointed at tools/ref_harness.sized_scenario_class (ONLY make_world replaced) before the envs are built;
-DCEnv, MultiAgentEnv, CoverageWorld, the vec-env wrappers, make_env and the Learner run unmodified.  To keep the file small the
-observation rows are stored for the first rollout only (the env is pinned elsewhere; the states behind the rows are implied by
-actions + masks).
+DCEnv, MultiAgentEnv, CoverageWorld, the vec-env wrappers, make_env and the Learner run unmodified.  To keep the files small the
+observation rows are stored for the first training rollout (and, at 4 x 20, the first eval rollout) only.
 
 Nothing of the reference is modified: the class is driven through its public `train()`; the only instrumentation is
   * a wrapper around the bound `learner.rollout` / `learner.rl_update` that snapshots the buffers / parameters after each call,
@@ -32,7 +31,7 @@ Contents (k = rollout call in order of execution, i = iteration 1..4):
   cfg_json                         the merged configuration
   init/actor/*, init/critic/*      parameters the run starts from
   r<k>/kind (0 train, 1 eval), r<k>/iter, r<k>/eps [T,E,N,2] f64, r<k>/mean, r<k>/std, r<k>/actions, r<k>/action_log_probs,
-  r<k>/rewards, r<k>/masks, r<k>/value_preds, r<k>/returns, r<k>/obs [T+1,E,N,D] f32, r<k>/info_reward, r<k>/info_coverage_rate,
+  r<k>/rewards, r<k>/masks, r<k>/value_preds, r<k>/returns, r<k>/obs [T+1,E,N,D] f32 (k = 0, 2 only), r<k>/info_reward, r<k>/info_coverage_rate,
   r<k>/vn_* ValueNorm state the returns were computed with
   i<i>/lr_actor, lr_critic (after lr_decay), i<i>/info_* (rl_update's dict), i<i>/vn_* (after the update),
   i<i>/actor/*, i<i>/critic/* (parameters after the update), i<i>/masks0 (slot 0 after after_update)
@@ -148,8 +147,8 @@ def main(E, N=None, M=None, rnn=False, mb=1):
                        if rnn else {}),
                     pre + "info_reward": np.array(float(info["reward"])),
                     pre + "info_coverage_rate": np.array(float(info["coverage_rate"]))})
-        if not sized or state["k"] == 0:
-            out[pre + "obs"] = r_buffer.obs.copy()
+        if state["k"] in ((0,) if sized else (0, 2)):     # rows of the first training rollout (+ the first eval rollout): the env itself
+            out[pre + "obs"] = r_buffer.obs.copy()          # is pinned elsewhere, later rollouts are covered by rewards / returns
         assert np.array_equal(r_buffer.share_obs[:, :, 0], r_buffer.obs.reshape(T + 1, Eb, -1))
         state["k"] += 1
         return info
