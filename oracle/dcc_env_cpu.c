@@ -212,3 +212,67 @@ DCC_API int dcc_obs_expand_cpu(dcc_env *env, int64_t n, const double *pos, const
     return DCC_OK;
 }
 
+/* The twins of dcc_obs_features / dcc_obs_features_x (include/dcc_env.h): the compact policy-input features of n states, defined by
+ * the observation rows of coverage.py:99-110 -- head = the first 4 + 2(N-1) columns of every row, poi_feat = the agent-independent
+ * (energy, done) columns, stats = (mean, sum of squared deviations) of the D float32 values of every row in float64 (two passes),
+ * cstats = the same moments of the centralised row pooled from the per-row moments, xa / xc = the input matrices of the per-env
+ * GEMMs of the structured first layers ([energy | done | 1 | 0..], [head_0..head_{N-1} | energy | done | 1 | 0..], rows padded to a
+ * multiple of 8 floats).  Any output may be NULL.  No counterpart in the reference beyond the rows themselves; here so that a
+ * caller of the shipped (state-only, structured-input) configuration can swap libraries like for every other entry point. */
+static int pad8(int k) { return (k + 7) / 8 * 8; }
+
+DCC_API int dcc_obs_features_x_cpu(dcc_env *env, int64_t n, const double *pos, const double *vel, const float *energy, const uint8_t *done,
+                                   float *head, float *poi_feat, double *stats, double *cstats, float *xa, float *xc, void *stream)
+{
+    (void)stream;
+    dcc_env_cpu *c = (dcc_env_cpu *)env;
+    if (!c) return cpu_fail(DCC_EINVAL, "dcc_obs_features_cpu: null env");
+    if (n < 1 || !pos || !vel || !energy || !done) return cpu_fail(DCC_EINVAL, "dcc_obs_features_cpu: bad argument");
+    const dcc_oracle *o = c->o;
+    const int N = o->N, M = o->M, D = o->D, HD = 4 + 2 * (N - 1);
+    const int ka = pad8(2 * M + 1), kc = pad8(N * HD + 2 * M + 1);
+    float *rows = (float *)malloc(sizeof(float) * (size_t)N * D);
+    double *mean_i = (double *)malloc(sizeof(double) * N), *m2_i = (double *)malloc(sizeof(double) * N);
+    if (!rows || !mean_i || !m2_i) { free(rows); free(mean_i); free(m2_i); return cpu_fail(DCC_ENOMEM, "dcc_obs_features_cpu: out of memory"); }
+    int rc = DCC_OK;
+    for (int64_t s = 0; s < n && rc == DCC_OK; s++) {
+        rc = dcc_obs_expand_cpu(env, 1, pos + (size_t)s * N * 2, vel + (size_t)s * N * 2, energy + (size_t)s * M, done + (size_t)s * M, rows, NULL);
+        if (rc != DCC_OK) break;
+        for (int i = 0; i < N; i++) {
+            const float *r = rows + (size_t)i * D;
+            double sum = 0.0, m2 = 0.0;
+            for (int k = 0; k < D; k++) sum += (double)r[k];
+            const double mean = sum / (double)D;
+            for (int k = 0; k < D; k++) { const double d = (double)r[k] - mean; m2 += d * d; }
+            mean_i[i] = mean; m2_i[i] = m2;
+            if (head) memcpy(head + ((size_t)s * N + i) * HD, r, sizeof(float) * HD);
+            if (stats) { stats[((size_t)s * N + i) * 2] = mean; stats[((size_t)s * N + i) * 2 + 1] = m2; }
+            if (xc) memcpy(xc + (size_t)s * kc + (size_t)i * HD, r, sizeof(float) * HD);
+        }
+        if (cstats) {
+            double mc = 0.0, m2c = 0.0;
+            for (int i = 0; i < N; i++) mc += mean_i[i];
+            mc /= (double)N;
+            for (int i = 0; i < N; i++) m2c += m2_i[i] + (double)D * (mean_i[i] - mc) * (mean_i[i] - mc);
+            cstats[(size_t)s * 2] = mc; cstats[(size_t)s * 2 + 1] = m2c;
+        }
+        const float *en = energy + (size_t)s * M;
+        const uint8_t *dn = done + (size_t)s * M;
+        for (int j = 0; j < M; j++) {
+            const float e = en[j], d = dn[j] ? 1.0f : 0.0f;
+            if (poi_feat) { poi_feat[(size_t)s * 2 * M + j] = e; poi_feat[(size_t)s * 2 * M + M + j] = d; }
+            if (xa) { xa[(size_t)s * ka + j] = e; xa[(size_t)s * ka + M + j] = d; }
+            if (xc) { xc[(size_t)s * kc + N * HD + j] = e; xc[(size_t)s * kc + N * HD + M + j] = d; }
+        }
+        if (xa) { xa[(size_t)s * ka + 2 * M] = 1.0f; for (int k = 2 * M + 1; k < ka; k++) xa[(size_t)s * ka + k] = 0.0f; }
+        if (xc) { xc[(size_t)s * kc + N * HD + 2 * M] = 1.0f; for (int k = N * HD + 2 * M + 1; k < kc; k++) xc[(size_t)s * kc + k] = 0.0f; }
+    }
+    free(rows); free(mean_i); free(m2_i);
+    return rc;
+}
+
+DCC_API int dcc_obs_features_cpu(dcc_env *env, int64_t n, const double *pos, const double *vel, const float *energy, const uint8_t *done,
+                                 float *head, float *poi_feat, double *stats, double *cstats, void *stream)
+{
+    return dcc_obs_features_x_cpu(env, n, pos, vel, energy, done, head, poi_feat, stats, cstats, NULL, NULL, stream);
+}

@@ -176,6 +176,7 @@ class CpuTwinEnv:
         L.dcc_env_get_state_cpu.argtypes = [vp] * 6
         L.dcc_env_set_state_cpu.argtypes = [vp] * 6
         L.dcc_obs_expand_cpu.argtypes = [vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp]
+        L.dcc_obs_features_x_cpu.argtypes = [vp, ctypes.c_int64] + [vp] * 11
         L.dcc_last_error_cpu.restype = ctypes.c_char_p
         self.L = L
         cfg = dcc_hip.EnvCfg()
@@ -255,6 +256,30 @@ class CpuTwinEnv:
         if rc != 0:
             raise RuntimeError("dcc_obs_expand_cpu failed: %d" % rc)
         return obs
+
+    def feature_shapes(self, n):
+        HD = 4 + 2 * (self.N - 1)
+        ka, kc = (2 * self.M + 1 + 7) // 8 * 8, (self.N * HD + 2 * self.M + 1 + 7) // 8 * 8
+        return dict(head=((n, self.N, HD), np.float32), poi_feat=((n, 2 * self.M), np.float32), stats=((n, self.N, 2), np.float64),
+                    cstats=((n, 2), np.float64), xa=((n, ka), np.float32), xc=((n, kc), np.float32))
+
+    def obs_features(self, pos, vel, energy, done, out=None):
+        """dcc_obs_features_x_cpu: the compact policy-input features of n states (same names / shapes as dcc_hip's obs_features);
+        `out`: a dict naming the outputs wanted (missing keys are skipped)."""
+        c = lambda a, t: np.ascontiguousarray(a, t)
+        pos, vel, energy, done = c(pos, np.float64), c(vel, np.float64), c(energy, np.float32), c(done, np.uint8)
+        n = pos.shape[0]
+        if out is None:
+            out = {k: np.empty(sh, dt) for k, (sh, dt) in self.feature_shapes(n).items()}
+        for k, (sh, dt) in self.feature_shapes(n).items():
+            a = out.get(k)
+            assert a is None or (a.shape == sh and a.dtype == dt and a.flags["C_CONTIGUOUS"]), k
+        g = lambda k: _p(out.get(k))
+        rc = self.L.dcc_obs_features_x_cpu(self._h, n, _p(pos), _p(vel), _p(energy), _p(done), g("head"), g("poi_feat"), g("stats"),
+                                           g("cstats"), g("xa"), g("xc"), None)
+        if rc != 0:
+            raise RuntimeError("dcc_obs_features_x_cpu failed: %d" % rc)
+        return out
 
     def get_state(self):
         st = dict(pos=np.empty((self.E, self.N, 2)), vel=np.empty((self.E, self.N, 2)), energy=np.empty((self.E, self.M), np.float32),

@@ -1,5 +1,5 @@
 """TEST-ONLY: lets the package's host logic (Learner, vec-env, rollout buffer, trainer) run on a box WITHOUT a GPU by standing the
-`_cpu` twins of the C-ABI (oracle/libdcc_oracle.so: dcc_env_*_cpu, dcc_obs_expand_cpu, dcc_gae_compute_cpu -- the C restatement of
+`_cpu` twins of the C-ABI (oracle/libdcc_oracle.so: dcc_env_*_cpu, dcc_obs_expand_cpu, dcc_obs_features_x_cpu, dcc_gae_compute_cpu -- the C restatement of
 the reference behind the same structs) in for the two device entry points the learner needs: `dcc_hip.HipCoverageEnv` and
 `dcc_hip.gae_compute`.  Everything above them is the product's own code on torch CPU tensors.
 
@@ -66,6 +66,21 @@ class TwinAsHipEnv(object):
             return rows
         obs.copy_(rows.view_as(obs))
         return obs
+
+    def feature_shapes(self, n):
+        tt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}
+        return {k: (sh, tt[np.dtype(dt)]) for k, (sh, dt) in self._t.feature_shapes(n).items()}
+
+    def alloc_features(self, n=None, keys=("head", "stats", "cstats", "xa", "xc")):
+        return {k: torch.empty(sh, dtype=dt) for k, (sh, dt) in self.feature_shapes(n or self.E).items() if k in keys}
+
+    def obs_features(self, pos, vel, energy, done, out=None):
+        """dcc_obs_features_x_cpu; `out`: dict of destination tensors (missing keys are skipped), like dcc_hip's."""
+        if out is None:
+            out = {k: torch.empty(sh, dtype=dt) for k, (sh, dt) in self.feature_shapes(pos.shape[0]).items()}
+        self._t.obs_features(pos.numpy(), vel.numpy(), energy.numpy(), done.numpy(),
+                             {k: t.numpy() for k, t in out.items() if t is not None})
+        return out
 
 
 def _gae_compute(rewards, value_preds, masks, denorm, gamma, gae_lambda, returns, advantages=None):

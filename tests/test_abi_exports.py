@@ -51,12 +51,14 @@ def test_library_exports_nothing_the_headers_do_not_declare():
 def test_cpu_twins_cover_the_reference_path_entry_points():
     """oracle/libdcc_oracle.so carries a `_cpu` twin (same signature, host pointers) of the entry points that
     stand for reference functions: the env life cycle / step / rollout / state of include/dcc_env.h and the GAE scan of
-    include/dcc_gae.h.  the observation rows from a state (dcc_obs_expand) (The remaining declarations are device utilities without a reference counterpart --
-    kernel choice, write probe, the compact policy-input features -- checked against the oracle's rows / the torch formulation instead.)"""
+    include/dcc_gae.h, the observation rows from a state (dcc_obs_expand) and, since round 5, their reduction to the compact policy-input
+    features (dcc_obs_features / _x).  (The remaining declarations are device utilities without a reference counterpart -- kernel choice,
+    write probe, the one-launch step + features, the trunk / loss / optimizer kernels -- checked against the torch formulation instead.)"""
     from oracle import oracle
     L = ctypes.CDLL(oracle.build())
     for n in ("dcc_env_create", "dcc_env_destroy", "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout",
-              "dcc_env_get_state", "dcc_env_set_state", "dcc_last_error", "dcc_obs_expand", "dcc_gae_compute"):
+              "dcc_env_get_state", "dcc_env_set_state", "dcc_last_error", "dcc_obs_expand", "dcc_obs_features", "dcc_obs_features_x",
+              "dcc_gae_compute"):
         assert n in _declared() and hasattr(L, n + "_cpu"), n
 
 

@@ -177,3 +177,54 @@ def test_gae_one_binding_two_libraries(T, C, use_vn, oracle_mod):
                         torch.from_numpy(dn).to(dev) if use_vn else None, 0.99, 0.95, ret_g, adv_g)
     np.testing.assert_array_equal(ret_g.cpu().numpy(), ret_c)
     np.testing.assert_array_equal(adv_g.cpu().numpy(), adv_c)
+
+
+# ---- include/dcc_env.h: dcc_obs_features / dcc_obs_features_x (oracle/dcc_env_cpu.c) --------------------------------------------
+def _states(N, M, n, seed):
+    rs = np.random.RandomState(seed)
+    return (rs.uniform(-1.2, 1.2, (n, N, 2)), rs.uniform(-0.5, 0.5, (n, N, 2)), rs.randint(0, 7, (n, M)).astype(np.float32),
+            (rs.uniform(size=(n, M)) < 0.3).astype(np.uint8))
+
+
+@pytest.mark.parametrize("N,M", [(4, 20), (8, 64), (5, 37), (1, 9)])
+def test_features_cpu_twin_is_the_reduction_of_the_rows(N, M, oracle_mod):
+    """dcc_obs_features_x_cpu(state) == the same quantities derived from the rows dcc_obs_expand_cpu builds of that state (the
+    package's own row-side formulation, algos/algo_utils/structured.features_from_obs / env_gemm_inputs): head and PoI columns
+    bit-equal, float64 row moments, the GEMM input matrices with their ones column and zero padding."""
+    import torch
+    from algos.algo_utils.structured import ObsLayout, env_gemm_inputs, features_from_obs
+    n = 11
+    poi = np.random.RandomState(M).uniform(-1, 1, (M, 2))
+    env = oracle_mod.CpuTwinEnv(3, N, M, poi, 0.25, 0.3, 0.95, 0.0)
+    st = _states(N, M, n, 3 * N + M)
+    f = env.obs_features(*st)
+    rows = torch.from_numpy(env.expand_obs(*st))
+    ref = features_from_obs(rows, ObsLayout(N, M, poi, 5.0))
+    assert np.array_equal(f["head"], ref["head"].numpy()) and np.array_equal(f["poi_feat"], ref["poi_feat"].numpy())
+    np.testing.assert_allclose(f["stats"], ref["stats"].numpy(), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(f["cstats"], ref["cstats"].numpy(), rtol=1e-11, atol=1e-13)
+    assert np.array_equal(f["xa"], env_gemm_inputs(ref, False).numpy()) and np.array_equal(f["xc"], env_gemm_inputs(ref, True).numpy())
+    only = env.obs_features(*st, out=dict(cstats=np.empty((n, 2))))              # any output may be NULL
+    assert set(only) == {"cstats"} and np.array_equal(only["cstats"], f["cstats"])
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,M", [(8, 64), (5, 37), (16, 256)])
+def test_features_one_binding_two_libraries(N, M, oracle_mod):
+    """dcc_obs_features_x (device pointers) and dcc_obs_features_x_cpu (host pointers) on the same states: float32 outputs bit-equal,
+    float64 moments to 1e-12 (the kernel sums across lanes, the twin along the row)."""
+    import torch
+    import dcc_hip
+    n = 29
+    poi = np.random.RandomState(N).uniform(-1, 1, (M, 2))
+    gpu = dcc_hip.HipCoverageEnv(4, N, M, poi, 0.25, 0.3, 0.95, 0.0)
+    cpu = oracle_mod.CpuTwinEnv(4, N, M, poi, 0.25, 0.3, 0.95, 0.0)
+    st = _states(N, M, n, N + M)
+    fg = gpu.obs_features(*[torch.from_numpy(a).to(gpu.device) for a in st])
+    fc = cpu.obs_features(*st)
+    for k in ("head", "poi_feat", "xa", "xc"):
+        assert np.array_equal(fg[k].cpu().numpy(), fc[k]), k
+    np.testing.assert_allclose(fg["stats"].cpu().numpy(), fc["stats"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(fg["cstats"].cpu().numpy(), fc["cstats"], rtol=1e-10, atol=1e-13)
+    gpu.close(); cpu.close()

@@ -90,13 +90,14 @@ def test_learner_replays_the_reference_learner(fixture, storage, capsys):
     _replay(fixture, storage, True, capsys)
 
 
-@pytest.mark.parametrize("fixture,storage", [(f, s) for f in ("e1", "e2", "e2_n8m64", "e2_mb2") for s in ("rows", "state-only")] + [("e2_rnn", "rows")])
+@pytest.mark.parametrize("fixture,storage", [(f, s) for f in ("e1", "e2", "e2_n8m64", "e2_mb2") for s in ("rows", "state-only", "shipped")]
+                         + [("e2_rnn", "rows")])
 def test_orchestrator_replays_the_reference_learner_on_the_cpu(fixture, storage, capsys, oracle_mod):
     """The same replay without a GPU: the package's Learner / vec-env / buffer / trainer on torch CPU tensors, with the `_cpu` twins
     of the C-ABI standing in for the two device entry points (tests/_cpu_twin_backend.py).  Pins the host-side orchestration --
     what learner.py:132-300 does between the kernels -- in the build container; the kernels themselves are the -m gpu run's job.
-    Row storage and the state-only buffer with regenerated rows (dcc_obs_expand_cpu); dense first layers (the structured ones
-    need dcc_obs_features, which has no twin)."""
+    Row storage, the state-only buffer with regenerated rows (dcc_obs_expand_cpu), and the SHIPPED configuration -- state-only
+    storage + structured first layers fed by dcc_obs_features_x_cpu (the fused trunk kernels in their torch formulation)."""
     from _cpu_twin_backend import cpu_twin_backend
     with cpu_twin_backend():
         _replay(fixture, storage, False, capsys)
