@@ -393,8 +393,8 @@ class MAPPOTrainer:
         permutation of the T*E*N agent rows, cut into num_mini_batch row sets; one ppo_update -- ValueNorm update on that
         set's returns (Q11), losses as means over the set, clip, Adam -- per set.  Same code for every storage mode: the
         buffer hands out rows, regenerated rows or state features (SharedReplayBuffer.minibatch_rows).
-        `self.minibatch_perms` (a list, consumed front to back) injects the permutations; otherwise torch.randperm on the CPU
-        generator, which is what the reference draws from."""
+        `self.minibatch_perms` (a list, consumed front to back) injects the permutations; otherwise the buffer draws them
+        (torch.randperm: on the CPU generator -- what the reference draws from -- when running on the CPU, on the device else)."""
         acc = torch.zeros(6, dtype=torch.float64, device=ptu.device)
         n_updates = 0
         # No activation of a mini-batch may reach 2^31 elements (see train(): a torch kernel of the backward pass faults beyond
