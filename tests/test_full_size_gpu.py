@@ -74,8 +74,7 @@ def test_full_shard_fused_rollout(name, N, M, E, cfs, r_comm, K, chunk, oracle_m
     rew, done, cov = np.concatenate(rew), np.concatenate(done), np.concatenate(cov)
     last_obs = out["obs"][-1].cpu().numpy()
     # (1) sampled envs against the oracle: first / last env, both envs of a roles workgroup, workgroup and XCD boundaries
-    sample = sorted(set([0, 1, 2, 3, 7, 8, 9, 63, 64, 255, 256, E // 2 - 1, E // 2, E - 2, E - 1]
-                        + list(np.random.RandomState(N).randint(0, E, 9))))
+    sample = _oracle_sample(E, N)
     exact = 0
     for e in sample:
         orc = oracle_mod.OracleEnv(1, N, M, poi, 0.2, r_comm, 0.95, cfs)
@@ -91,6 +90,96 @@ def test_full_shard_fused_rollout(name, N, M, E, cfs, r_comm, K, chunk, oracle_m
         assert exact == len(sample)          # no transcendental in the path: the rows are bit-identical
     assert int(done.sum()) >= 0 and np.isfinite(rew).all()
     env.close()
+
+
+def _oracle_sample(E, N, extra=9):
+    return sorted(set([0, 1, 2, 3, 7, 8, 9, 63, 64, 255, 256, E // 2 - 1, E // 2, E - 2, E - 1]
+                      + list(np.random.RandomState(N).randint(0, E, extra))))
+
+
+def test_bench_kernel_form_hbm_actions_full_occupancy(oracle_mod):
+    """The exact launch bench.py's headline times: `dcc_env_rollout` over 8 UAV x 64 PoI x 4096 envs, K = 150 fused steps, the
+    action stream READ FROM HBM (a [K,E,N,2] f32 tensor -> kernel form <ACT=0,false,8,64>, two envs per workgroup), rows +
+    assignment + per-step scalars written, no state outputs (bench.py `run`: env.alloc_out(T, obs, assign) / env.rollout(T,
+    actions=...)).  The tensor holds the oracle's action stream, so the launch must reproduce (a) the in-kernel-stream launch of
+    the same seed (ACT = 2, the form the other full-size tests run) bit for bit in every output, and (b) the CPU oracle on
+    sampled envs.  Reference work unit: envs/mpe/multiagent/environment.py:86-110, CoverageWorld.py:57-68."""
+    import dcc_hip
+    N, M, E, K, seed = 8, 64, 4096, 150, 28
+    poi = _pois(M)
+    acts = np.stack([oracle_mod.rng_actions(seed, k, E, N) for k in range(K)])          # [K,E,N,2] f32: the oracle's stream
+    a = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, 0.40, 0.95, 0.0)
+    b = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, 0.40, 0.95, 0.0)
+    # (nothing forced: the launch resolves to whatever dcc_env_create picked on this box, which is what bench.py times too)
+    a.reset(); b.reset()
+    oa = a.alloc_out(K, obs=True, assign=True)                     # what bench.py allocates (plus the f64 reward for the oracle)
+    oa["reward64"] = torch.empty(K, E, dtype=torch.float64, device=a.device)
+    ob = dict(b.alloc_out(K, obs=True, assign=True), reward64=torch.empty(K, E, dtype=torch.float64, device=b.device))
+    a.rollout(K, actions=torch.from_numpy(acts).cuda(), out=oa)     # ACT = 0: actions from HBM
+    b.rollout(K, seed=seed, step0=0, env0=0, env_total=E, out=ob)    # ACT = 2: in-kernel stream
+    for k in oa:
+        assert torch.equal(oa[k], ob[k]), k
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    rew, done, cov = oa["reward64"].cpu().numpy(), oa["done"].cpu().numpy(), oa["coverage"].cpu().numpy()
+    last_obs, assign = oa["obs"][-1].cpu().numpy(), oa["assign"].cpu().numpy()
+    assert int(done.sum()) > 0                                       # episodes ended and restarted inside the launch
+    for e in _oracle_sample(E, N):
+        orc = oracle_mod.OracleEnv(1, N, M, poi, 0.2, 0.40, 0.95, 0.0)
+        orc.reset()
+        rows = []
+        for k in range(K):
+            ref = orc.step(acts[k, e][None], want_obs=(k == K - 1))
+            assert done[k, e] == ref["done"][0] and cov[k, e] == np.float32(ref["coverage"][0]), (e, k)
+            np.testing.assert_allclose(rew[k, e], ref["reward"][0], rtol=1e-9, atol=1e-7, err_msg="env %d step %d" % (e, k))
+            assert np.array_equal(assign[k, e], ref["assign"][0]), (e, k)
+        assert np.array_equal(last_obs[e], ref["obs"][0].astype(np.float32)), e          # no transcendental: bit-identical rows
+        orc.close()
+    a.close(); b.close()
+
+
+def test_step_features_full_occupancy(oracle_mod):
+    """`dcc_env_step_features` -- the ONE launch per step of the learner's policy-driven rollout on the shipped configuration --
+    at the c3 occupancy (8 x 64 x 4096 envs, one launch per step, actions from HBM): every per-step output, the emitted
+    compact state and every feature tensor equal, bit for bit, `dcc_env_step` + `dcc_obs_features_x` on a second env object,
+    over 150 steps with auto-resets; the stepped state equals the CPU oracle's on sampled envs."""
+    import dcc_hip
+    N, M, E, T, seed = 8, 64, 4096, 150, 31
+    poi = _pois(M)
+    a = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, 0.40, 0.95, 0.0)
+    b = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, 0.40, 0.95, 0.0)
+    a.reset(); b.reset()
+    keys = ("reward", "done", "connect", "connect_s", "coverage", "assign", "state_pos", "state_vel", "state_energy", "state_done")
+    mk = lambda env: {**env.alloc_out(obs=False), **env.alloc_state_out()}
+    oa, ob = mk(a), mk(b)
+    fb = b.alloc_features(keys=("head", "poi_feat", "stats", "cstats", "xa", "xc"))
+    sample = _oracle_sample(E, N, extra=3)
+    orcs = {e: oracle_mod.OracleEnv(1, N, M, poi, 0.2, 0.40, 0.95, 0.0) for e in sample}
+    for o in orcs.values():
+        o.reset()
+    resets = 0
+    for t in range(T):
+        acts = oracle_mod.rng_actions(seed, t, E, N)
+        act = torch.from_numpy(acts).cuda()
+        a.step(act, oa)
+        fa = a.obs_features(oa["state_pos"], oa["state_vel"], oa["state_energy"], oa["state_done"])
+        b.step_features(act, ob, fb)
+        for k in keys:
+            assert torch.equal(oa[k], ob[k]), (k, t)
+        for k in fb:
+            assert torch.equal(fa[k], fb[k]), (k, t)
+        resets += int(ob["done"].sum())
+        pos, en, dn = ob["state_pos"].cpu().numpy(), ob["state_energy"].cpu().numpy(), ob["done"].cpu().numpy()
+        for e, o in orcs.items():
+            ref = o.step(acts[e][None], want_obs=False)
+            st = o.get_state()
+            assert dn[e] == ref["done"][0] and np.array_equal(pos[e], st["pos"][0]), (e, t)
+            assert np.array_equal(en[e], st["energy"][0].astype(np.float32)), (e, t)
+    assert resets > 0
+    for o in orcs.values():
+        o.close()
+    a.close(); b.close()
 
 
 def test_full_size_c3_iteration():

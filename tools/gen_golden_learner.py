@@ -8,6 +8,19 @@ eval_interval).  Container-only (needs /root/reference); the outputs are data.  
     python tools/gen_golden_learner.py 2 8 64 # the BASELINE c2 / c3 task size (8 UAV x 64 PoI) -> learner_ref_e2_n8m64.npz
     python tools/gen_golden_learner.py 2 rnn  # use_recurrent_policy: true (GRU actor / critic)  -> learner_ref_e2_rnn.npz
     python tools/gen_golden_learner.py 2 mb2  # num_mini_batch: 2 (row mini-batches in every epoch) -> learner_ref_e2_mb2.npz
+    python tools/gen_golden_learner.py 2 8 64 h256   # 8 x 64 at the SHIPPED width, algo_hidden_size 256, ppo_epoch 2
+                                                      # -> learner_ref_e2_n8m64_h256.npz (after gen_golden_mappo_env.py n8m64_h256)
+
+h256: the ~1 M initial parameters are not stored a second time: the run starts from the `actor/` / `critic/` parameters of
+tests/golden/mappo_env_n8m64_h256.npz (loaded into the reference's networks before training, like the action-mean bias below),
+and the parameters after each iteration are kept as sampled snapshots (tests/_sampling.py: 4,096 elements + max|delta| +
+||delta||_2 per tensor, against the previous iteration and against the start).  ppo_epoch is 2 there (as in the
+mappo_env_* fixtures), not 15: at width 256 on a 640-row batch the reference's own longer updates are chaotic at the 1-ulp
+level.  tools/h256_fixture_sensitivity.sh (-> profiles/r06/h256_fixture_sensitivity.txt) runs the reference with its initial
+parameters scaled by 1 + 1e-7 N(0,1), six noise seeds: with 15 epochs every seed moves single elements of the iteration-2
+update by 9e-2 ... 2e-1 of max|delta| and ||delta||_2 by 9e-3; with 5 (3) epochs one seed in six bifurcates (elements 0.59
+(0.22), ||delta||_2 1.8e-2 (7.6e-4)); with 2 epochs all six stay within 2.0e-3 / 8.4e-6 over the whole run -- the only
+trajectory other arithmetic orders can be held to a tight bar on.  (`ep<k>`, `pert=<x>`, `seed=<n>`, `out=<dir>`: probe flags.)
 
 The third form needs the size-generalised scenario: the shipped one hard-codes 4 x 20 in make_world (coverage.py:40-41), so
 `scenarios.load` is pointed at tools/ref_harness.sized_scenario_class (ONLY make_world replaced) before the envs are built;
@@ -48,6 +61,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference/uav_dcc_control"
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "..", "tests", "_standin"))        # omegaconf stand-in (PyYAML-backed container)
+sys.path.insert(1, os.path.join(HERE, "..", "tests"))
+from _sampling import snapshot  # noqa: E402
 from ref_harness import _install_gym_stub  # noqa: E402
 
 
@@ -69,8 +84,9 @@ def vn_np(vn, prefix, out):
     out[prefix + "vn_debias"] = vn.debiasing_term.numpy().copy()
 
 
-def main(E, N=None, M=None, rnn=False, mb=1):
+def main(E, N=None, M=None, rnn=False, mb=1, h256=False, epochs=2, pert=0.0, outdir=None, pert_seed=1):
     _stub_modules()
+    init_file = os.path.join(HERE, "..", "tests", "golden", "mappo_env_n8m64_h256.npz")
     sized = N is not None
     os.chdir(REF)                         # the reference resolves ./config/... and ./envs/... relative to its own directory
     sys.path.insert(0, REF)
@@ -88,6 +104,10 @@ def main(E, N=None, M=None, rnn=False, mb=1):
     cfg.algo_hidden_size = 32
     cfg.n_iters = 4
     cfg.eval_interval = 2
+    if h256:
+        assert (N, M) == (8, 64), "h256 starts from the parameters of mappo_env_n8m64_h256.npz"
+        cfg.algo_hidden_size = 256
+        cfg.ppo_epoch = epochs
     if mb > 1:     # the reference's mini-batch loop (mappo.py:203-213 over shared_buffer.py:239-279); the permutations it draws with
         cfg.num_mini_batch = mb              # torch.randperm are recorded (i<i>/perms [ppo_epoch, T*E*N])
     if rnn:        # the reference's recurrent branch of the orchestrator: GRU states in collect / insert (zeroed on episode ends,
@@ -103,10 +123,25 @@ def main(E, N=None, M=None, rnn=False, mb=1):
     learner = Learner(cfg)
     out = {"cfg_json": np.array(json.dumps(OmegaConf.to_container(cfg, resolve=True), default=str))}
 
+    if h256:
+        Zi = np.load(init_file)
+        for mod, pre in ((learner.policy.actor, "actor/"), (learner.policy.critic, "critic/")):
+            mod.load_state_dict({k[len(pre):]: torch.from_numpy(Zi[k]) for k in Zi.files if k.startswith(pre)}, strict=True)
     with torch.no_grad():
         learner.policy.actor.act.action_out.fc_mean.bias.copy_(torch.tensor([1.2, 0.15]))
-    sd_np(learner.policy.actor, "init/actor/", out)
-    sd_np(learner.policy.critic, "init/critic/", out)
+    if pert:      # sensitivity probe only (never for a committed fixture): relative 1-ulp-sized noise on the initial parameters
+        g = torch.Generator().manual_seed(pert_seed)
+        with torch.no_grad():
+            for p in list(learner.policy.actor.parameters()) + list(learner.policy.critic.parameters()):
+                p.mul_(1.0 + pert * torch.randn(p.shape, generator=g))
+    init_np = {}
+    sd_np(learner.policy.actor, "init/actor/", init_np)
+    sd_np(learner.policy.critic, "init/critic/", init_np)
+    if h256:      # only what differs from the file the parameters came from
+        out["init/actor/act.action_out.fc_mean.bias"] = init_np["init/actor/act.action_out.fc_mean.bias"]
+    else:
+        out.update(init_np)
+    prev_np = dict(init_np)
 
     rec = {"on": False, "mean": [], "std": []}
 
@@ -172,8 +207,14 @@ def main(E, N=None, M=None, rnn=False, mb=1):
         for k, v in info.items():
             out[pre + "info_" + k] = np.array(float(v))
         vn_np(learner.trainer.value_normalizer, pre, out)
-        sd_np(learner.policy.actor, pre + "actor/", out)
-        sd_np(learner.policy.critic, pre + "critic/", out)
+        if h256:
+            for tag, mod in (("actor/", learner.policy.actor), ("critic/", learner.policy.critic)):
+                now = {k: v.detach().numpy().copy() for k, v in mod.state_dict().items()}
+                snapshot(out, pre + tag, now, {k: prev_np["init/" + tag + k] for k in now}, {k: init_np["init/" + tag + k] for k in now})
+                prev_np.update({"init/" + tag + k: v for k, v in now.items()})
+        else:
+            sd_np(learner.policy.actor, pre + "actor/", out)
+            sd_np(learner.policy.critic, pre + "critic/", out)
         out[pre + "masks0"] = learner.rl_buffer.masks[0].copy()
         return info
 
@@ -182,8 +223,9 @@ def main(E, N=None, M=None, rnn=False, mb=1):
     learner.train()
 
     out["dims"] = np.array([E, N, learner.cfg.num_pois, T, learner.cfg.algo_hidden_size, learner.cfg.n_iters, state["k"]])
-    path = os.path.join(HERE, "..", "tests", "golden", "learner_ref_e%d%s%s%s.npz" % (E, "_n%dm%d" % (N, M) if sized else "", "_rnn" if rnn else "",
-                                                                                     "_mb%d" % mb if mb > 1 else ""))
+    assert outdir or (not pert and epochs == 2 and pert_seed == 1), "probe runs must not overwrite the committed fixture: pass out=<dir>"
+    path = os.path.join(outdir or os.path.join(HERE, "..", "tests", "golden"), "learner_ref_e%d%s%s%s.npz" % (E, "_n%dm%d" % (N, M) if sized else "", "_rnn" if rnn else "",
+                                                                                     ("_mb%d" % mb if mb > 1 else "") + ("_h256" if h256 else "")))
     np.savez_compressed(path, **out)
     ends = [int((out["r%d/masks" % k][1:, :, 0, 0] == 0).sum()) for k in range(state["k"])]
     print("wrote", os.path.normpath(path), os.path.getsize(path) // 1024, "KB; rollouts:", state["k"], "kinds:",
@@ -193,6 +235,9 @@ def main(E, N=None, M=None, rnn=False, mb=1):
 
 
 if __name__ == "__main__":
-    flags = [a for a in sys.argv[1:] if a == "rnn" or a.startswith("mb")]
+    flags = [a for a in sys.argv[1:] if a in ("rnn", "h256") or a.startswith(("mb", "ep", "pert=", "out=", "seed="))]
     argv = [a for a in sys.argv[1:] if a not in flags]
-    main(*([int(v) for v in argv[:3]] or [2]), rnn="rnn" in flags, mb=max([int(a[2:]) for a in flags if a.startswith("mb")] or [1]))
+    opt = lambda pre, conv, default: ([conv(a[len(pre):]) for a in flags if a.startswith(pre)] or [default])[0]
+    main(*([int(v) for v in argv[:3]] or [2]), rnn="rnn" in flags, mb=opt("mb", int, 1), h256="h256" in flags,
+         epochs=opt("ep", int, 2), pert=opt("pert=", float, 0.0), outdir=opt("out=", str, None),
+         pert_seed=opt("seed=", int, 1))

@@ -1,9 +1,13 @@
 """Generate tests/golden/mappo_env_small.npz: the REFERENCE MAPPO update (algos.mappo / buffer.shared_buffer / utils.valuenorm
 imported from /root/reference/uav_dcc_control) on a rollout of the REFERENCE env (tools/ref_harness.py), i.e. with real
 observation rows -- the fixture the structured-input path (first layers from env-state features) is checked against directly.
-Container-only; the outputs are data.  Re-run: python tools/gen_golden_mappo_env.py [small|n8m64|n12m24|small_mb2|n8m64_mb3]
+Container-only; the outputs are data.  Re-run: python tools/gen_golden_mappo_env.py [small|n8m64|n12m24|small_mb2|n8m64_mb3|n8m64_h256]
 (`*_mb<k>`: the same rollouts with num_mini_batch = k -- the reference's row mini-batches; the permutations it drew are stored)
 Second case `n8m64` (tests/golden/mappo_env_n8m64.npz): the BASELINE c2/c3 shape, 8 UAV x 64 PoI, E=2, T=31, hidden 32.
+`n8m64_h256`: the n8m64 rollout with the SHIPPED width, algo_hidden_size 256 (config/algo_config/mappo.yaml) -- the kernel
+instantiations and tuned GEMM picks BASELINE c3 runs.  The ~1 M initial parameters are stored in full, the post-update ones as
+sampled snapshots (tests/_sampling.py: 4,096 elements + max|delta| + ||delta||_2 per tensor); `fwd_*` holds the reference
+networks' own forward on the stored rollout (values, log-probs / entropy of the stored actions) before the update.
 Third case `n12m24`: 12 UAVs (more than 8: the learner's first block forms head . Wh^T with a library GEMM), 24 PoI, E=2, T=20.
 
 4 UAV x 20 PoI (shipped world constants), E=3 envs, T=34 steps (env 1 flies east and finishes at step 30: one episode end + auto-reset), hidden 32, ppo_epoch 2.  Contents:
@@ -23,6 +27,8 @@ import yaml
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "..", "tests"))
+from _sampling import snapshot  # noqa: E402
 from ref_harness import make_reference_env  # noqa: E402  (installs the gym stub, puts the reference on sys.path)
 
 REF = "/root/reference/uav_dcc_control"
@@ -30,7 +36,8 @@ CASES = {"small": (4, 20, 3, 34, 32), "n8m64": (8, 64, 2, 31, 32), "n12m24": (12
          # [, num_mini_batch]: the reference's feed_forward_generator with more than one mini-batch (shared_buffer.py:239-279):
          # per epoch one torch.randperm over the T*E*N agent rows, cut into num_mini_batch row sets, one ppo_update (and one
          # ValueNorm update, Q11) per set.  The permutations the run drew are stored as perm<epoch>.
-         "small_mb2": (4, 20, 3, 34, 32, 2), "n8m64_mb3": (8, 64, 2, 31, 32, 3)}
+         "small_mb2": (4, 20, 3, 34, 32, 2), "n8m64_mb3": (8, 64, 2, 31, 32, 3),
+         "n8m64_h256": (8, 64, 2, 32, 256)}
 
 
 class Box:
@@ -130,6 +137,15 @@ def main(case="small"):
     out["value_preds_after"] = buf.value_preds.copy()
     adv = buf.returns[:-1] - vn.denormalize(buf.value_preds[:-1])
     out["adv_norm"] = (adv - np.nanmean(adv)) / (np.nanstd(adv) + 1e-5)
+    if H >= 256:      # the reference networks' forward on the stored rollout, before the update (policy.evaluate_actions,
+        trainer.prep_rollout()           # mappo.py:84-99 -> r_actor_critic.py:60-75,110-121): values [T*E*N,1], log-probs, entropy
+        with torch.no_grad():
+            B = T * E * N
+            v, lp, ent = policy.evaluate_actions(buf.share_obs[:-1].reshape(B, S), buf.obs[:-1].reshape(B, D),
+                                                 buf.rnn_states[:-1].reshape(B, *buf.rnn_states.shape[3:]),
+                                                 buf.rnn_states_critic[:-1].reshape(B, *buf.rnn_states_critic.shape[3:]),
+                                                 buf.actions.reshape(B, A), buf.masks[:-1].reshape(B, 1))
+        out.update(fwd_values=v.numpy().copy(), fwd_log_probs=lp.numpy().copy(), fwd_entropy=np.array(float(ent)))
     trainer.prep_training()
     torch.manual_seed(3)
     perms, randperm = [], torch.randperm
@@ -150,10 +166,12 @@ def main(case="small"):
             out["perm%d" % i] = p.astype(np.int64)
     for k, v in info.items():
         out["info_" + k] = np.array(float(v))
-    for k, v in policy.actor.state_dict().items():
-        out["actor2/" + k] = v.numpy().copy()
-    for k, v in policy.critic.state_dict().items():
-        out["critic2/" + k] = v.numpy().copy()
+    for pre, mod in (("actor", policy.actor), ("critic", policy.critic)):
+        after = {k: v.numpy().copy() for k, v in mod.state_dict().items()}
+        if H >= 256:
+            snapshot(out, pre + "2s/", after, {k: out[pre + "/" + k] for k in after})
+        else:
+            out.update({pre + "2/" + k: v for k, v in after.items()})
     out.update(vn1_mean=vn.running_mean.numpy().copy(), vn1_mean_sq=vn.running_mean_sq.numpy().copy(),
                vn1_debias=vn.debiasing_term.numpy().copy())
     out["dims"] = np.array([N, M, E, T, A, H, D] + ([MB] if MB > 1 else []))
