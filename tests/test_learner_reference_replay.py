@@ -220,8 +220,9 @@ def _replay(fixture, storage, gpu, capsys):
             trk.close("info_%s@%d" % (key, i), info[key], Z[pre + "info_" + key], 1e-4,
                       scale=max(abs(float(Z[pre + "info_" + key])), 0.1 if key == "policy_loss" else 0.0))
         vn = lr.trainer.value_normalizer
-        trk.close("vn_mean@%d" % i, vn.running_mean.cpu().numpy(), Z[pre + "vn_mean"], 1e-5)
-        trk.close("vn_mean_sq@%d" % i, vn.running_mean_sq.cpu().numpy(), Z[pre + "vn_mean_sq"], 1e-5)
+        w = 1.0 if i == 1 else LATER        # moments of the returns: from iteration 2 on those of this run's own rollouts (see rollout)
+        trk.close("vn_mean@%d" % i, vn.running_mean.cpu().numpy(), Z[pre + "vn_mean"], 1e-5 * w)
+        trk.close("vn_mean_sq@%d" % i, vn.running_mean_sq.cpu().numpy(), Z[pre + "vn_mean_sq"], 1e-5 * w)
         trk.close("vn_debias@%d" % i, vn.debiasing_term.cpu().numpy(), Z[pre + "vn_debias"], 1e-6)
         np.testing.assert_array_equal(lr.rl_buffer.masks[0].cpu().numpy(), Z[pre + "masks0"])
         for tag, mod, rtag in (("a", lr.policy.actor, "actor/"), ("c", lr.policy.critic, "critic/")):
