@@ -126,9 +126,11 @@ class SharedReplayBuffer(object):
         self.n_rollout_threads = cfg.n_rollout_threads
         self.num_agents = cfg.num_agents
         self.gamma, self.gae_lambda = cfg.gamma, cfg.gae_lambda
-        self._use_gae, self._use_valuenorm = cfg.use_gae, cfg.use_valuenorm
-        if cfg.use_popart or cfg.use_proper_time_limits or not cfg.use_gae:
-            raise NotImplementedError("only the reference's live branch (GAE, no PopArt, no proper time limits) is built")
+        self._use_gae, self._use_valuenorm = bool(cfg.use_gae), cfg.use_valuenorm
+        self._use_proper_time_limits = bool(cfg.use_proper_time_limits)
+        if cfg.use_popart:
+            raise NotImplementedError("use_popart: disabled in the reference config and not built (the reference's PopArt.update "
+                                      "raises TypeError on its first call, algo_utils/popart.py:60-63)")
         T, E, N = self.episode_length, self.n_rollout_threads, self.num_agents
         D = get_shape_from_obs_space(obs_space)[0]
         S = get_shape_from_obs_space(cent_obs_space)[0]
@@ -392,17 +394,27 @@ class SharedReplayBuffer(object):
 
     # ---- returns --------------------------------------------------------------------------------------------
     def compute_returns(self, next_value, value_normalizer=None):
-        """GAE(gamma, lambda) on denormalised values, reverse scan segmented by `masks`
-        (shared_buffer.py:199-208) -- one launch of dcc_gae_compute.  Also fills `advantages_raw`
-        = returns - denorm(value_preds) (mappo.py:191)."""
+        """shared_buffer.py:160-217 as one launch of the backward scan: GAE(gamma, lambda) on denormalised values segmented by
+        `masks` (the shipped branch, :199-208 -> dcc_gae_compute), with use_proper_time_limits the `bad_masks` variants
+        (:167-197) and without use_gae the plain discounted returns (:186-197, :214-217) -> dcc_returns_compute.  Also fills
+        `advantages_raw` = returns - denorm(value_preds) (mappo.py:191)."""
         import dcc_hip
         T, E, N = self.episode_length, self.n_rollout_threads, self.num_agents
-        nv = self._t(next_value)
-        self.value_preds[-1].copy_(nv.view(E, -1, 1).expand_as(self.value_preds[-1]))
+        nv = self._t(next_value).view(E, -1, 1)
         denorm = value_normalizer.denorm_params() if (value_normalizer is not None and self._use_valuenorm) else None
-        dcc_hip.gae_compute(self.rewards.view(T, E * N), self.value_preds.view(T + 1, E * N),
-                            self.masks.view(T + 1, E * N), denorm, self.gamma, self.gae_lambda,
-                            self.returns.view(T + 1, E * N), self.advantages_raw.view(T, E * N))
+        flat = lambda x: x.view(x.shape[0], E * N)
+        if self._use_gae:
+            self.value_preds[-1].copy_(nv.expand_as(self.value_preds[-1]))              # :169,200
+        else:
+            self.returns[-1].copy_(nv.expand_as(self.returns[-1]))                      # :187,215 (value_preds[-1] is not set)
+        if self._use_gae and not self._use_proper_time_limits:
+            dcc_hip.gae_compute(flat(self.rewards), flat(self.value_preds), flat(self.masks), denorm, self.gamma, self.gae_lambda,
+                                flat(self.returns), flat(self.advantages_raw))
+            return
+        mode = (dcc_hip.RETURNS_GAE if self._use_gae else 0) | (dcc_hip.RETURNS_PROPER if self._use_proper_time_limits else 0)
+        dcc_hip.returns_compute(flat(self.rewards), flat(self.value_preds), flat(self.masks),
+                                flat(self.bad_masks) if self._use_proper_time_limits else None, denorm, self.gamma,
+                                self.gae_lambda, mode, flat(self.returns), flat(self.advantages_raw))
 
     # ---- sampling -----------------------------------------------------------------------------------------------
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None, dedup_critic=False, perm=None,

@@ -44,7 +44,7 @@ class ObsFeat(ctypes.Structure):       # include/dcc_env.h: dcc_obs_feat
     _fields_ = [("head", _vp), ("poi_feat", _vp), ("stats", _vp), ("cstats", _vp), ("xa", _vp), ("xc", _vp)]
 
 
-EXPORTS = ["dcc_obs_expand", "dcc_gae_compute", "dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
+EXPORTS = ["dcc_obs_expand", "dcc_gae_compute", "dcc_returns_compute", "dcc_abi_version", "dcc_last_error", "dcc_env_cfg_default", "dcc_env_create", "dcc_env_destroy",
            "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_step_features", "dcc_env_obs_write_probe", "dcc_env_rollout", "dcc_env_get_state",
            "dcc_env_set_state", "dcc_env_bytes_per_step", "dcc_env_kernel_choice", "dcc_obs_features", "dcc_obs_features_x",
            "dcc_relu_ln_fwd", "dcc_relu_ln_bwd", "dcc_relu_ln_head_fwd", "dcc_relu_ln_head_bwd", "dcc_mlp_workspace_floats", "dcc_actor_l1_fwd", "dcc_actor_l1_bwd", "dcc_actor_l1_pre_fwd", "dcc_actor_l1_pre_bwd",
@@ -85,6 +85,8 @@ def load_library(path=None):
     L.dcc_env_step_features.argtypes = [_vp, _vp, ctypes.c_int, ctypes.POINTER(EnvOut), ctypes.POINTER(ObsFeat), _vp]
     L.dcc_gae_compute.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, ctypes.c_int32,
                                   ctypes.c_int64, _vp]
+    L.dcc_returns_compute.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int32, _vp, _vp,
+                                      ctypes.c_int32, ctypes.c_int64, _vp]
     L.dcc_obs_expand.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]
     L.dcc_obs_features.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     L.dcc_obs_features_x.argtypes = [_vp, ctypes.c_int64] + [_vp] * 11
@@ -454,6 +456,34 @@ def gae_compute(rewards, value_preds, masks, denorm, gamma, gae_lambda, returns,
         rc = L.dcc_gae_compute(_ptr(rewards), _ptr(value_preds), _ptr(masks), _ptr(denorm), float(gamma),
                                float(gae_lambda), _ptr(returns), _ptr(advantages), T, C, _stream())
     _check(rc, "dcc_gae_compute")
+    return returns
+
+RETURNS_GAE, RETURNS_PROPER = 1, 2     # include/dcc_gae.h: DCC_RETURNS_GAE, DCC_RETURNS_PROPER
+
+
+def returns_compute(rewards, value_preds, masks, bad_masks, denorm, gamma, gae_lambda, mode, returns, advantages=None):
+    """include/dcc_gae.h: dcc_returns_compute -- every branch of the reference's compute_returns (mode = RETURNS_GAE |
+    RETURNS_PROPER bits).  Tensors as for gae_compute plus bad_masks [T+1,C] (None without RETURNS_PROPER); without RETURNS_GAE
+    row T of `returns` must hold the bootstrap value.  No CPU path."""
+    L = load_library()
+    T, C = rewards.shape
+    ts = [("rewards", rewards, (T, C)), ("value_preds", value_preds, (T + 1, C)), ("masks", masks, (T + 1, C)),
+          ("returns", returns, (T + 1, C))]
+    if bad_masks is not None:
+        ts.append(("bad_masks", bad_masks, (T + 1, C)))
+    if advantages is not None:
+        ts.append(("advantages", advantages, (T, C)))
+    if denorm is not None:
+        ts.append(("denorm", denorm, (2,)))
+    for name, t, shape in ts:
+        if not t.is_cuda:
+            raise DccError("returns_compute: %s is not on a HIP device (there is no CPU path)" % name)
+        if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shape or t.device != rewards.device:
+            raise ValueError("returns_compute: %s must be contiguous float32 %s on %s" % (name, shape, rewards.device))
+    with torch.cuda.device(rewards.device):
+        rc = L.dcc_returns_compute(_ptr(rewards), _ptr(value_preds), _ptr(masks), _ptr(bad_masks), _ptr(denorm), float(gamma),
+                                   float(gae_lambda), int(mode), _ptr(returns), _ptr(advantages), T, C, _stream())
+    _check(rc, "dcc_returns_compute")
     return returns
 
 

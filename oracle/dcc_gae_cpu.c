@@ -48,3 +48,61 @@ DCC_API int dcc_gae_compute_cpu(const float *rewards, const float *value_preds, 
     }
     return 0;
 }
+
+
+/*
+ * dcc_returns_compute_cpu -- twin of dcc_returns_compute: every branch of SharedReplayBuffer.compute_returns
+ * (buffer/shared_buffer.py:160-217), one column at a time, float32 in the reference's operation order:
+ *   use_proper_time_limits, use_gae   :167-185   delta as in the live branch;
+ *                                                with ValueNorm  gae = delta + gamma * gae_lambda * gae * masks[step+1]   (:176)
+ *                                                without         gae = delta + gamma * gae_lambda * masks[step+1] * gae   (:183)
+ *                                                gae = gae * bad_masks[step+1];  returns[step] = gae + denorm(value_preds[step])
+ *   use_proper_time_limits, no gae    :186-197   returns[-1] = next_value;
+ *                                                returns[step] = (returns[step+1] * gamma * masks[step+1] + rewards[step]) * bad_masks[step+1]
+ *                                                                + (1 - bad_masks[step+1]) * denorm(value_preds[step])
+ *   neither                           :214-217   returns[-1] = next_value;  returns[step] = returns[step+1] * gamma * masks[step+1] + rewards[step]
+ *   use_gae only                      :199-213   dcc_gae_compute_cpu above
+ * Pinned bit-exact to tests/golden/returns_modes.npz (the reference's own loops, tools/gen_golden_returns.py).
+ */
+DCC_API int dcc_returns_compute_cpu(const float *rewards, const float *value_preds, const float *masks, const float *bad_masks,
+                                    const float *denorm, double gamma, double gae_lambda, int32_t mode, float *returns,
+                                    float *advantages, int32_t T, int64_t C, void *stream)
+{
+    if (mode == DCC_RETURNS_GAE)
+        return dcc_gae_compute_cpu(rewards, value_preds, masks, denorm, gamma, gae_lambda, returns, advantages, T, C, stream);
+    if (mode < 0 || mode > (DCC_RETURNS_GAE | DCC_RETURNS_PROPER)) return -1;
+    if (!rewards || !value_preds || !masks || !returns) return -1;
+    if ((mode & DCC_RETURNS_PROPER) && !bad_masks) return -1;
+    if (T < 1 || C < 1) return -1;
+    const int use_gae = (mode & DCC_RETURNS_GAE) != 0, ptl = (mode & DCC_RETURNS_PROPER) != 0;
+    const float g = (float)gamma, gl = (float)(gamma * gae_lambda);
+    const int dn = denorm != NULL;
+    const float mean = dn ? denorm[0] : 0.f, sd = dn ? denorm[1] : 1.f;
+    for (int64_t c = 0; c < C; ++c) {
+        float carry = use_gae ? value_preds[(int64_t)T * C + c] : returns[(int64_t)T * C + c];
+        if (use_gae && dn) carry = carry * sd + mean;
+        float gae = 0.f;
+        for (int32_t t = T - 1; t >= 0; --t) {
+            const float r = rewards[(int64_t)t * C + c], m = masks[(int64_t)(t + 1) * C + c];
+            const float b = ptl ? bad_masks[(int64_t)(t + 1) * C + c] : 1.f;
+            float v_cur = value_preds[(int64_t)t * C + c];
+            if (dn) v_cur = v_cur * sd + mean;
+            float ret;
+            if (use_gae) {
+                const float delta = (r + (g * carry) * m) - v_cur;
+                if (dn) gae = delta + (gl * gae) * m;                /* :176 */
+                else gae = delta + (gl * m) * gae;                   /* :183 */
+                gae = gae * b;                                       /* :177,184 */
+                ret = gae + v_cur;
+                carry = v_cur;
+            } else {
+                const float disc = (carry * g) * m + r;
+                ret = ptl ? disc * b + (1.f - b) * v_cur : disc;     /* :190-197 | :217 */
+                carry = ret;
+            }
+            returns[(int64_t)t * C + c] = ret;
+            if (advantages) advantages[(int64_t)t * C + c] = ret - v_cur;
+        }
+    }
+    return 0;
+}

@@ -39,3 +39,48 @@ def compute_returns_gae(rewards, value_preds, masks, next_value, gamma, gae_lamb
         gae = delta + gamma * gae_lambda * masks[step + 1] * gae
         returns[step] = gae + denorm(vp[step])
     return returns, vp
+
+
+def compute_returns(rewards, value_preds, masks, bad_masks, next_value, gamma, gae_lambda, use_gae, use_proper_time_limits,
+                    mean=None, std=None):
+    """Every branch of buffer/shared_buffer.py:160-217 in numpy float32, statement by statement (mean / std None: the
+    `else` arms without ValueNorm).  Returns (returns [T+1,...], value_preds as the method leaves them).  Pinned against
+    tests/golden/returns_modes.npz (tools/gen_golden_returns.py ran the reference's own method for the 8 flag combinations)."""
+    rewards = np.asarray(rewards, np.float32)
+    vp = np.array(value_preds, np.float32, copy=True)
+    masks, bad_masks = np.asarray(masks, np.float32), np.asarray(bad_masks, np.float32)
+    T = rewards.shape[0]
+    returns = np.zeros_like(vp)
+    vn = mean is not None
+
+    def denorm(v):
+        return v * np.float32(std) + np.float32(mean)
+
+    if use_proper_time_limits:
+        if use_gae:
+            vp[-1] = next_value
+            gae = 0
+            for step in reversed(range(T)):
+                if vn:                                                                                       # :171-178
+                    delta = rewards[step] + gamma * denorm(vp[step + 1]) * masks[step + 1] - denorm(vp[step])
+                    gae = delta + gamma * gae_lambda * gae * masks[step + 1]
+                    gae = gae * bad_masks[step + 1]
+                    returns[step] = gae + denorm(vp[step])
+                else:                                                                                        # :180-185
+                    delta = rewards[step] + gamma * vp[step + 1] * masks[step + 1] - vp[step]
+                    gae = delta + gamma * gae_lambda * masks[step + 1] * gae
+                    gae = gae * bad_masks[step + 1]
+                    returns[step] = gae + vp[step]
+        else:
+            returns[-1] = next_value
+            for step in reversed(range(T)):                                                                  # :188-197
+                v = denorm(vp[step]) if vn else vp[step]
+                returns[step] = (returns[step + 1] * gamma * masks[step + 1] + rewards[step]) * bad_masks[step + 1] \
+                    + (1 - bad_masks[step + 1]) * v
+    else:
+        if use_gae:
+            return compute_returns_gae(rewards, vp, masks, next_value, gamma, gae_lambda, mean, std)        # :199-213
+        returns[-1] = next_value
+        for step in reversed(range(T)):                                                                      # :215-217
+            returns[step] = returns[step + 1] * gamma * masks[step + 1] + rewards[step]
+    return returns, vp

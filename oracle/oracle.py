@@ -63,6 +63,8 @@ def lib():
         L.dcc_oracle_rollout_rng.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
                                              ctypes.c_int, vp, vp, vp, vp]
         L.dcc_gae_compute_cpu.argtypes = [vp, vp, vp, vp, ctypes.c_double, ctypes.c_double, vp, vp, ctypes.c_int32, ctypes.c_int64, vp]
+        L.dcc_returns_compute_cpu.argtypes = [vp, vp, vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_int32, vp, vp,
+                                              ctypes.c_int32, ctypes.c_int64, vp]
         _lib = L
     return _lib
 
@@ -80,6 +82,21 @@ def gae_compute_cpu(rewards, value_preds, masks, denorm, gamma, gae_lambda, retu
                                    _p(returns), _p(advantages), T, C, None)
     if rc != 0:
         raise RuntimeError("dcc_gae_compute_cpu failed: %d" % rc)
+    return returns
+
+
+def returns_compute_cpu(rewards, value_preds, masks, bad_masks, denorm, gamma, gae_lambda, mode, returns, advantages=None):
+    """The `_cpu` twin of include/dcc_gae.h's dcc_returns_compute (mode: DCC_RETURNS_GAE = 1 | DCC_RETURNS_PROPER = 2); arrays as
+    for gae_compute_cpu plus bad_masks [T+1,C] (None without DCC_RETURNS_PROPER)."""
+    T, C = rewards.shape
+    for a, shape in ((rewards, (T, C)), (value_preds, (T + 1, C)), (masks, (T + 1, C)), (returns, (T + 1, C)),
+                     (bad_masks, (T + 1, C)), (advantages, (T, C))):
+        assert a is None or (a.dtype == np.float32 and a.flags.c_contiguous and a.shape == shape)
+    dn = None if denorm is None else np.ascontiguousarray(denorm, np.float32)
+    rc = lib().dcc_returns_compute_cpu(_p(rewards), _p(value_preds), _p(masks), _p(bad_masks), _p(dn), float(gamma), float(gae_lambda),
+                                       int(mode), _p(returns), _p(advantages), T, C, None)
+    if rc != 0:
+        raise RuntimeError("dcc_returns_compute_cpu failed: %d" % rc)
     return returns
 
 

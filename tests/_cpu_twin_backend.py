@@ -1,5 +1,5 @@
 """TEST-ONLY: lets the package's host logic (Learner, vec-env, rollout buffer, trainer) run on a box WITHOUT a GPU by standing the
-`_cpu` twins of the C-ABI (oracle/libdcc_oracle.so: dcc_env_*_cpu, dcc_obs_expand_cpu, dcc_obs_features_x_cpu, dcc_gae_compute_cpu -- the C restatement of
+`_cpu` twins of the C-ABI (oracle/libdcc_oracle.so: dcc_env_*_cpu, dcc_obs_expand_cpu, dcc_obs_features_x_cpu, dcc_gae_compute_cpu, dcc_returns_compute_cpu -- the C restatement of
 the reference behind the same structs) in for the two device entry points the learner needs: `dcc_hip.HipCoverageEnv` and
 `dcc_hip.gae_compute`.  Everything above them is the product's own code on torch CPU tensors.
 
@@ -93,14 +93,24 @@ def _gae_compute(rewards, value_preds, masks, denorm, gamma, gae_lambda, returns
     return returns
 
 
+def _returns_compute(rewards, value_preds, masks, bad_masks, denorm, gamma, gae_lambda, mode, returns, advantages=None):
+    from oracle import oracle
+    n = lambda t: None if t is None else t.detach().numpy()
+    for t in (rewards, value_preds, masks, bad_masks, returns, advantages):
+        assert t is None or (t.is_contiguous() and t.dtype == torch.float32)
+    oracle.returns_compute_cpu(n(rewards), n(value_preds), n(masks), n(bad_masks), None if denorm is None else n(denorm.contiguous()),
+                               gamma, gae_lambda, mode, n(returns), n(advantages))
+    return returns
+
+
 @contextlib.contextmanager
 def cpu_twin_backend():
     import dcc_hip
     from oracle import oracle
     oracle.build()
-    saved = dcc_hip.HipCoverageEnv, dcc_hip.gae_compute
-    dcc_hip.HipCoverageEnv, dcc_hip.gae_compute = TwinAsHipEnv, _gae_compute
+    saved = dcc_hip.HipCoverageEnv, dcc_hip.gae_compute, dcc_hip.returns_compute
+    dcc_hip.HipCoverageEnv, dcc_hip.gae_compute, dcc_hip.returns_compute = TwinAsHipEnv, _gae_compute, _returns_compute
     try:
         yield
     finally:
-        dcc_hip.HipCoverageEnv, dcc_hip.gae_compute = saved
+        dcc_hip.HipCoverageEnv, dcc_hip.gae_compute, dcc_hip.returns_compute = saved

@@ -58,7 +58,7 @@ def test_cpu_twins_cover_the_reference_path_entry_points():
     L = ctypes.CDLL(oracle.build())
     for n in ("dcc_env_create", "dcc_env_destroy", "dcc_env_obs_dim", "dcc_env_reset", "dcc_env_step", "dcc_env_rollout",
               "dcc_env_get_state", "dcc_env_set_state", "dcc_last_error", "dcc_obs_expand", "dcc_obs_features", "dcc_obs_features_x",
-              "dcc_gae_compute"):
+              "dcc_gae_compute", "dcc_returns_compute"):
         assert n in _declared() and hasattr(L, n + "_cpu"), n
 
 
