@@ -136,7 +136,7 @@ class MAPPOTrainer:
         self.data_chunk_length = int(getattr(cfg, "data_chunk_length", 10))
         # reference quirk Q4 (doubled surrogate) on by default; critic de-duplication is exact
         self.double_surrogate = bool(getattr(cfg, "double_surrogate", True))
-        self.dedup_critic = bool(getattr(cfg, "dedup_critic", True))
+        self.dedup_critic = bool(getattr(cfg, "dedup_critic", True)) and bool(getattr(cfg, "use_centralized_V", True))
         # compute the parameter-free part of the input LayerNorm once per train() instead of once per epoch
         self.cache_normalized_inputs = bool(getattr(cfg, "cache_normalized_inputs", True))
         # > 0: visit the batch in chunks of this many rollout steps with gradient accumulation (exact);

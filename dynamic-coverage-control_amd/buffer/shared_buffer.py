@@ -136,7 +136,13 @@ class SharedReplayBuffer(object):
         S = get_shape_from_obs_space(cent_obs_space)[0]
         A = get_shape_from_act_space(act_space)
         self.obs_dim, self.share_obs_dim, self.act_dim = D, S, A
-        self._shared_is_view = (S == N * D)
+        # use_centralized_V: false -- the "shared" observation IS the agent's own row (learner.py:43-46,221-222,272-273): one
+        # critic input per agent row, `share_obs` is `obs`
+        self.decentralized = not bool(getattr(cfg, "use_centralized_V", True))
+        if self.decentralized and (S != D or compact or featurizer is not None):
+            raise ValueError("use_centralized_V: false needs the observation space as cent_obs_space and row storage "
+                             "(structured_input: false, compact_obs: false)")
+        self._shared_is_view = (S == N * D) and not self.decentralized
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
         self.compact = bool(compact)
         # structured input (algos/algo_utils/structured.py): the policy consumes compact features of the state
@@ -163,7 +169,7 @@ class SharedReplayBuffer(object):
             self._chunk_obs = None
         else:
             self.obs = z(T + 1, E, N, D).as_subclass(_RowTensor)
-        self._share_obs = None if (self._shared_is_view or self.compact) else z(T + 1, E, S)
+        self._share_obs = None if (self._shared_is_view or self.compact or self.decentralized) else z(T + 1, E, S)
         self.value_preds = z(T + 1, E, N, 1)
         self.returns = z(T + 1, E, N, 1)
         self.advantages_raw = z(T, E, N, 1)
@@ -321,6 +327,9 @@ class SharedReplayBuffer(object):
             return (f, f, None, None, rows(self.actions), rows(self.value_preds), rows(self.returns),
                     rows(self.masks), rows(self.active_masks), rows(self.action_log_probs), rows(adv), None)
         obs = self.obs_rows(t0, t1)
+        if self.decentralized:
+            return (obs.reshape(n * N, -1), obs.reshape(n * N, -1), None, None, rows(self.actions), rows(self.value_preds),
+                    rows(self.returns), rows(self.masks), rows(self.active_masks), rows(self.action_log_probs), rows(adv), None)
         so_env = obs.reshape(n, N * self.obs_dim) if (self._shared_is_view or self.compact) else self._share_obs[t0:t1].reshape(n, -1)
         so = so_env if dedup_critic else so_env.unsqueeze(1).expand(-1, N, -1).reshape(n * N, -1)
         return (so, obs.reshape(n * N, -1), None, None, rows(self.actions), rows(self.value_preds), rows(self.returns),
@@ -332,6 +341,8 @@ class SharedReplayBuffer(object):
         """[T+1, E, S]: one centralised observation per env (what the critic is fed with dedup_critic)."""
         if self.compact:
             raise RuntimeError("compact buffer: use share_obs_env_at(t) / chunk_sample()")
+        if self.decentralized:
+            raise RuntimeError("use_centralized_V: false -- there is no per-env centralised observation; the critic reads buffer.obs")
         if self._shared_is_view:
             T1, E, N, D = self.obs.shape
             return self.obs.view(T1, E, N * D)
@@ -340,8 +351,8 @@ class SharedReplayBuffer(object):
     @property
     def share_obs(self):
         """[T+1, E, N, S] with the reference's shape and no memory: reads are expanded views (state-only buffer:
-        regenerated per step), writes go where `_Rows` says."""
-        return _Rows(self, shared=True)
+        regenerated per step), writes go where `_Rows` says.  use_centralized_V: false: the observation rows themselves."""
+        return self.obs if self.decentralized else _Rows(self, shared=True)
 
     # ---- writing -----------------------------------------------------------------------------------------
     def _t(self, x):
@@ -356,7 +367,7 @@ class SharedReplayBuffer(object):
         if obs is not None:
             dst = self.obs_slot(s + 1)
             dst.copy_(self._t(obs).view_as(dst))
-        if share_obs is not None and not self._shared_is_view:
+        if share_obs is not None and not self._shared_is_view and not self.decentralized:
             so = self._t(share_obs)
             self._share_obs[s + 1].copy_(so[:, 0] if so.dim() == 3 else so)
         if self.recurrent and rnn_states_actor is not None:
@@ -432,6 +443,8 @@ class SharedReplayBuffer(object):
                 raise RuntimeError("compact buffer: the full batch is visited with chunk_sample() (ppo_update_chunked)")
             rows = lambda x: x.reshape(T * E * N, -1)
             adv = torch.as_tensor(advantages).to(self.device, torch.float32)
+            if self.decentralized and dedup_critic:
+                raise ValueError("use_centralized_V: false has one critic input per agent row: dedup_critic must be false")
             so = self.share_obs_env[:-1].reshape(T * E, -1) if dedup_critic else self.share_obs[:-1].reshape(T * E * N, -1)
             yield (so, rows(self.obs[:-1]), None, None, rows(self.actions), rows(self.value_preds[:-1]),
                    rows(self.returns[:-1]), rows(self.masks[:-1]), rows(self.active_masks[:-1]),
@@ -515,6 +528,10 @@ class SharedReplayBuffer(object):
                 return (so_env, obs, None, None) + tail + ((None, inv),)
             return (so_env[inv], obs, None, None) + tail
         obs = self.obs[:-1].reshape(B, -1)[rows]
+        if self.decentralized:
+            if dedup_critic:
+                raise ValueError("use_centralized_V: false has one critic input per agent row: dedup_critic must be false")
+            return (obs, obs, None, None) + tail
         so_env = self.share_obs_env[:-1].reshape(T * E, -1)
         if dedup_critic:
             if all_pairs:       # the stored centralised rows as they are (a view: nothing gathered)
@@ -532,7 +549,7 @@ class SharedReplayBuffer(object):
     def _rows(self, t, e, n, advantages):
         """The 12-tuple of the rows addressed by the index vectors (t, e, n); rnn states are filled in by the callers."""
         adv = torch.as_tensor(advantages).to(self.device, torch.float32)
-        so = self.share_obs_env[t, e]
+        so = self.obs[t, e, n] if self.decentralized else self.share_obs_env[t, e]
         return [so, self.obs[t, e, n], None, None, self.actions[t, e, n], self.value_preds[t, e, n], self.returns[t, e, n],
                 self.masks[t, e, n], self.active_masks[t, e, n], self.action_log_probs[t, e, n], adv[t, e, n], None]
 

@@ -51,6 +51,12 @@ class Learner:
             # the recurrent variants (off in the shipped config) consume observation rows step by step: the rollout buffer
             # keeps rows and per-(env, agent) GRU states, and the critic runs once per agent row like in the reference
             self.cfg.structured_input = self.cfg.compact_obs = False
+        self.use_centralized_V = bool(self.cfg.use_centralized_V)
+        if not self.use_centralized_V:
+            # use_centralized_V: false (learner.py:43-46,218-222,269-273): the critic reads each agent's OWN observation row,
+            # so there is one value per agent row and nothing to share between the agents of an env -- row storage, dense
+            # first layers, the critic on every row, like the reference
+            self.cfg.structured_input = self.cfg.compact_obs = self.cfg.dedup_critic = False
         self.rank, self.world = ptu.init_distributed() if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or ptu.single_rank_group()) else (0, 1)
         self.dist_on = self.world > 1 or ptu.single_rank_group()
         utl.seed(self.cfg.seed + self.rank)
@@ -75,10 +81,8 @@ class Learner:
                   % (self.cfg.save_name, self.train_envs.n_envs, self.world))
 
         # 2. policy / trainer
-        self.use_centralized_V = self.cfg.use_centralized_V
-        if not self.use_centralized_V:
-            raise NotImplementedError("use_centralized_V: false is not on the reference's shipped path")
-        self.share_observation_space = self.train_envs.share_observation_space[0]
+        self.share_observation_space = (self.train_envs.share_observation_space[0] if self.use_centralized_V
+                                        else self.train_envs.observation_space[0])          # learner.py:43-46
         from algos.mappo import MAPPOPolicy, MAPPOTrainer
         self.policy = MAPPOPolicy(self.cfg, self.train_envs.observation_space[0], self.share_observation_space,
                                   self.train_envs.action_space[0])
@@ -145,7 +149,8 @@ class Learner:
         bcfg.n_rollout_threads = envs.n_envs
         structured = bool(getattr(self.cfg, "structured_input", False))
         compact = bool(getattr(self.cfg, "compact_obs", False))
-        return SharedReplayBuffer(bcfg, envs.observation_space[0], envs.share_observation_space[0], envs.action_space[0],
+        return SharedReplayBuffer(bcfg, envs.observation_space[0],
+                                  envs.share_observation_space[0] if self.use_centralized_V else envs.observation_space[0], envs.action_space[0],
                                   compact=compact, n_pois=envs.n_pois, expander=envs.env.expand_obs if compact else None,
                                   featurizer=envs.env.obs_features if structured else None)
 
@@ -281,13 +286,16 @@ class Learner:
         if self.recurrent:          # learner.py:231-252 with the GRU states and masks of this step, one critic row per agent
             masks = r_buffer.masks[cur_step].reshape(E * N, 1)
             actions, logp, rnn_a = self.policy.actor(obs, r_buffer.rnn_states[cur_step].reshape(E * N, *r_buffer.rnn_states.shape[3:]), masks)
-            so = r_buffer.share_obs_env_at(cur_step).unsqueeze(1).expand(E, N, -1)     # a view per agent, no [T+1,E,N,S] accessor detour
+            so = (r_buffer.share_obs_env_at(cur_step).unsqueeze(1).expand(E, N, -1)     # a view per agent, no [T+1,E,N,S] accessor detour
+                  if self.use_centralized_V else obs)
             values, rnn_c = self.policy.critic(so.reshape(E * N, -1),
                                                r_buffer.rnn_states_critic[cur_step].reshape(E * N, *r_buffer.rnn_states.shape[3:]), masks)
             return (values.view(E, N, 1), actions.view(E, N, -1).contiguous(), logp.view(E, N, 1),
                     rnn_a.reshape(E, N, *rnn_a.shape[1:]), rnn_c.reshape(E, N, *rnn_c.shape[1:]))
         actions, logp, _ = self.policy.actor(obs)
-        if self.trainer.dedup_critic:
+        if not self.use_centralized_V:      # one value per agent row from its own observation (learner.py:221-222)
+            values = self.policy.critic(obs)[0].view(E, N, 1)
+        elif self.trainer.dedup_critic:
             values = self.policy.critic(r_buffer.share_obs_env_at(cur_step))[0].view(E, 1, 1).expand(E, N, 1)
         else:
             so = r_buffer.share_obs_env_at(cur_step).unsqueeze(1).expand(E, N, -1)
@@ -342,6 +350,10 @@ class Learner:
             next_values = self.policy.critic(r_buffer.share_obs[last].reshape(E * N, -1),
                                              r_buffer.rnn_states_critic[last].reshape(E * N, *r_buffer.rnn_states.shape[3:]),
                                              r_buffer.masks[last].reshape(E * N, 1))[0].view(E, N, 1)
+            r_buffer.compute_returns(next_values, self.trainer.value_normalizer)
+            return
+        if not self.use_centralized_V:
+            next_values = self.policy.critic(r_buffer.obs_at(last).view(E * N, -1))[0].view(E, N, 1)
             r_buffer.compute_returns(next_values, self.trainer.value_normalizer)
             return
         cent = r_buffer.features_at(last) if r_buffer.structured else r_buffer.share_obs_env_at(last)

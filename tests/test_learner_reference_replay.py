@@ -40,7 +40,7 @@ def _shipped_cfg(ref_cfg, **over):
     for f in ("config/env_config/dcc.yaml", "config/algo_config/mappo.yaml", "config/expt.yaml"):
         cfg.update(yaml.safe_load(open(os.path.join(PKG, f))))
     for k in ("n_rollout_threads", "max_ep_len", "algo_hidden_size", "n_iters", "eval_interval", "save_model", "log_wandb",
-              "num_agents", "num_pois", "use_recurrent_policy", "num_mini_batch") + (("ppo_epoch",) if ref_cfg["algo_hidden_size"] == 256 else ()):
+              "num_agents", "num_pois", "use_recurrent_policy", "num_mini_batch", "use_centralized_V", "use_gae") + (("ppo_epoch",) if ref_cfg["algo_hidden_size"] == 256 else ()):
         cfg[k] = ref_cfg[k]      # (ppo_epoch: 2 in the hidden-256 fixture, see tools/gen_golden_learner.py on why)
     for k, v in ref_cfg.items():
         if k in ("save_gifs",):
@@ -90,7 +90,7 @@ def _initial_parameters(Z, tag, module):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("storage", ["shipped", "rows"])
-@pytest.mark.parametrize("fixture", ["e1", "e2", "e2_n8m64", "e2_rnn", "e2_mb2", "e2_n8m64_h256"])
+@pytest.mark.parametrize("fixture", ["e1", "e2", "e2_n8m64", "e2_rnn", "e2_mb2", "e2_n8m64_h256", "e2_decv", "e2_nogae"])
 def test_learner_replays_the_reference_learner(fixture, storage, capsys):
     """e1 / e2: the shipped 4 UAV x 20 PoI task on 1 env (DummyVecEnv in the reference) / 2 envs (SubprocVecEnv); e2_n8m64: the
     BASELINE c2 / c3 task size, 8 UAV x 64 PoI, through the size-generalised scenario (tools/gen_golden_learner.py); e2_rnn:
@@ -99,12 +99,15 @@ def test_learner_replays_the_reference_learner(fixture, storage, capsys):
     falls back to row storage by itself for it; e2_mb2: `num_mini_batch: 2` -- 15 epochs x 2 row mini-batches per iteration, the
     reference's permutations injected (on the shipped state-only storage this is SURVEY.md 8f row 4 end to end);
     e2_n8m64_h256: the 8 x 64 task at the SHIPPED width algo_hidden_size 256, 3 iterations -- the rollout-step and update kernels
-    in the instantiations BASELINE c3 runs (parameter snapshots sampled: tests/_sampling.py)."""
+    in the instantiations BASELINE c3 runs (parameter snapshots sampled: tests/_sampling.py); e2_decv: `use_centralized_V: false`
+    -- the critic on each agent's own observation row (learner.py:43-46,218-222,269-273), one value per agent; like the GRU
+    variants the Learner falls back to row storage for it by itself; e2_nogae: `use_gae: false` -- compute_returns' plain
+    discounted returns (shared_buffer.py:214-217 -> dcc_returns_compute mode 0) through the orchestrator."""
     _replay(fixture, storage, True, capsys)
 
 
 @pytest.mark.parametrize("fixture,storage", [(f, s) for f in ("e1", "e2", "e2_n8m64", "e2_mb2") for s in ("rows", "state-only", "shipped")]
-                         + [("e2_rnn", "rows"), ("e2_n8m64_h256", "shipped")])
+                         + [("e2_rnn", "rows"), ("e2_n8m64_h256", "shipped"), ("e2_decv", "rows"), ("e2_decv", "shipped"), ("e2_nogae", "shipped")])
 def test_orchestrator_replays_the_reference_learner_on_the_cpu(fixture, storage, capsys, oracle_mod):
     """The same replay without a GPU: the package's Learner / vec-env / buffer / trainer on torch CPU tensors, with the `_cpu` twins
     of the C-ABI standing in for the two device entry points (tests/_cpu_twin_backend.py).  Pins the host-side orchestration --
@@ -145,7 +148,12 @@ def _replay(fixture, storage, gpu, capsys):
     from learner import Learner
     lr = Learner(_shipped_cfg(ref_cfg, **over))
     rnn = bool(ref_cfg["use_recurrent_policy"])
-    if rnn:       # recurrent policies read rows step by step: the Learner switches the shipped state-only storage off on its own
+    decv = not ref_cfg["use_centralized_V"]
+    if decv:      # one critic input per agent row: row storage, no de-duplication, whatever the YAMLs ask for
+        b = lr.rl_buffer
+        assert b.decentralized and not b.compact and not b.structured and not lr.trainer.dedup_critic and b.share_obs is b.obs
+        assert lr.policy.critic.base.mlp.fc1[0].in_features == b.obs_dim
+    elif rnn:     # recurrent policies read rows step by step: the Learner switches the shipped state-only storage off on its own
         assert lr.recurrent and not lr.rl_buffer.compact and not lr.rl_buffer.structured
     else:
         assert lr.rl_buffer.compact == (storage != "rows") and lr.rl_buffer.structured == (storage == "shipped")

@@ -8,6 +8,8 @@ eval_interval).  Container-only (needs /root/reference); the outputs are data.  
     python tools/gen_golden_learner.py 2 8 64 # the BASELINE c2 / c3 task size (8 UAV x 64 PoI) -> learner_ref_e2_n8m64.npz
     python tools/gen_golden_learner.py 2 rnn  # use_recurrent_policy: true (GRU actor / critic)  -> learner_ref_e2_rnn.npz
     python tools/gen_golden_learner.py 2 mb2  # num_mini_batch: 2 (row mini-batches in every epoch) -> learner_ref_e2_mb2.npz
+    python tools/gen_golden_learner.py 2 decv # use_centralized_V: false (critic on each agent's own row)  -> learner_ref_e2_decv.npz
+    python tools/gen_golden_learner.py 2 nogae # use_gae: false -> plain discounted returns (shared_buffer.py:214-217) -> learner_ref_e2_nogae.npz
     python tools/gen_golden_learner.py 2 8 64 h256   # 8 x 64 at the SHIPPED width, algo_hidden_size 256, ppo_epoch 2
                                                       # -> learner_ref_e2_n8m64_h256.npz (after gen_golden_mappo_env.py n8m64_h256)
 
@@ -84,7 +86,7 @@ def vn_np(vn, prefix, out):
     out[prefix + "vn_debias"] = vn.debiasing_term.numpy().copy()
 
 
-def main(E, N=None, M=None, rnn=False, mb=1, h256=False, epochs=2, pert=0.0, outdir=None, pert_seed=1):
+def main(E, N=None, M=None, rnn=False, mb=1, h256=False, decv=False, nogae=False, epochs=2, pert=0.0, outdir=None, pert_seed=1):
     _stub_modules()
     init_file = os.path.join(HERE, "..", "tests", "golden", "mappo_env_n8m64_h256.npz")
     sized = N is not None
@@ -108,6 +110,10 @@ def main(E, N=None, M=None, rnn=False, mb=1, h256=False, epochs=2, pert=0.0, out
         assert (N, M) == (8, 64), "h256 starts from the parameters of mappo_env_n8m64_h256.npz"
         cfg.algo_hidden_size = 256
         cfg.ppo_epoch = epochs
+    if decv:       # learner.py:43-46,218-222,269-273: the critic's input is each agent's own observation row
+        cfg.use_centralized_V = False
+    if nogae:      # compute_returns' last branch: returns[-1] = next_value, discounted sum segmented by masks (shared_buffer.py:214-217)
+        cfg.use_gae = False
     if mb > 1:     # the reference's mini-batch loop (mappo.py:203-213 over shared_buffer.py:239-279); the permutations it draws with
         cfg.num_mini_batch = mb              # torch.randperm are recorded (i<i>/perms [ppo_epoch, T*E*N])
     if rnn:        # the reference's recurrent branch of the orchestrator: GRU states in collect / insert (zeroed on episode ends,
@@ -184,7 +190,8 @@ def main(E, N=None, M=None, rnn=False, mb=1, h256=False, epochs=2, pert=0.0, out
                     pre + "info_coverage_rate": np.array(float(info["coverage_rate"]))})
         if state["k"] in ((0,) if sized else (0, 2)):     # rows of the first training rollout (+ the first eval rollout): the env itself
             out[pre + "obs"] = r_buffer.obs.copy()          # is pinned elsewhere, later rollouts are covered by rewards / returns
-        assert np.array_equal(r_buffer.share_obs[:, :, 0], r_buffer.obs.reshape(T + 1, Eb, -1))
+        assert np.array_equal(r_buffer.share_obs, r_buffer.obs) if decv else \
+            np.array_equal(r_buffer.share_obs[:, :, 0], r_buffer.obs.reshape(T + 1, Eb, -1))
         state["k"] += 1
         return info
 
@@ -225,7 +232,7 @@ def main(E, N=None, M=None, rnn=False, mb=1, h256=False, epochs=2, pert=0.0, out
     out["dims"] = np.array([E, N, learner.cfg.num_pois, T, learner.cfg.algo_hidden_size, learner.cfg.n_iters, state["k"]])
     assert outdir or (not pert and epochs == 2 and pert_seed == 1), "probe runs must not overwrite the committed fixture: pass out=<dir>"
     path = os.path.join(outdir or os.path.join(HERE, "..", "tests", "golden"), "learner_ref_e%d%s%s%s.npz" % (E, "_n%dm%d" % (N, M) if sized else "", "_rnn" if rnn else "",
-                                                                                     ("_mb%d" % mb if mb > 1 else "") + ("_h256" if h256 else "")))
+                                                                                     ("_mb%d" % mb if mb > 1 else "") + ("_h256" if h256 else "") + ("_decv" if decv else "") + ("_nogae" if nogae else "")))
     np.savez_compressed(path, **out)
     ends = [int((out["r%d/masks" % k][1:, :, 0, 0] == 0).sum()) for k in range(state["k"])]
     print("wrote", os.path.normpath(path), os.path.getsize(path) // 1024, "KB; rollouts:", state["k"], "kinds:",
@@ -235,9 +242,9 @@ def main(E, N=None, M=None, rnn=False, mb=1, h256=False, epochs=2, pert=0.0, out
 
 
 if __name__ == "__main__":
-    flags = [a for a in sys.argv[1:] if a in ("rnn", "h256") or a.startswith(("mb", "ep", "pert=", "out=", "seed="))]
+    flags = [a for a in sys.argv[1:] if a in ("rnn", "h256", "decv", "nogae") or a.startswith(("mb", "ep", "pert=", "out=", "seed="))]
     argv = [a for a in sys.argv[1:] if a not in flags]
     opt = lambda pre, conv, default: ([conv(a[len(pre):]) for a in flags if a.startswith(pre)] or [default])[0]
-    main(*([int(v) for v in argv[:3]] or [2]), rnn="rnn" in flags, mb=opt("mb", int, 1), h256="h256" in flags,
+    main(*([int(v) for v in argv[:3]] or [2]), rnn="rnn" in flags, mb=opt("mb", int, 1), h256="h256" in flags, decv="decv" in flags, nogae="nogae" in flags,
          epochs=opt("ep", int, 2), pert=opt("pert=", float, 0.0), outdir=opt("out=", str, None),
          pert_seed=opt("seed=", int, 1))
