@@ -15,7 +15,8 @@ byte contract of SURVEY.md section 8d (11,851 B per env-step at c2).  One step i
 
 Prints ONE JSON line on rank 0.  `roofline` is always measured live: HIP events around every timed
 launch on the launch stream.  `cpu_baseline` times the CPU oracle (oracle/dcc_oracle.c, "port") on
-the host cores, rank 0, N=1.  `c4` (unless --no-c3) is a bounded env-step leg at BASELINE configs[3]'s shape with the
+the host cores of the same box in the same run: rank 0, after the timed region, at every N (the other ranks of an N > 1 job wait
+at a barrier; `ranks_waiting` says how many).  `c4` (unless --no-c3) is a bounded env-step leg at BASELINE configs[3]'s shape with the
 job-wide env count fixed (16 UAV x 256 PoI x 8192 envs / N per GPU: strong scaling), `c5` the same for configs[4]
 (32 UAV x 1024 PoI x 16384 envs / N, connectivity pull force on).  `c3` (unless --no-c3) is a bounded run of BASELINE configs[2]: full
 MAPPO iterations (policy-driven rollout + HIP GAE + PPO epochs) at the same shape, with the RCCL
@@ -330,12 +331,16 @@ def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, la
     del env, out
     torch.cuda.empty_cache()
     extra = {}
-    if cpu is not None and rank == 0 and world == 1:
-        # the CPU restatement at THIS (N, M) through the same C-ABI twins, single thread and all threads
+    if cpu is not None and rank == 0:
+        # the CPU restatement at THIS (N, M) through the same C-ABI twins, single thread and all threads; in an
+        # N > 1 job the other ranks wait at the barrier below (idle GPUs, the host threads are rank 0's)
         try:
             extra["cpu_baseline"] = cpu_baseline(N, M, load_pois(M), 0.2, r_comm, 0.95, cfs, label=name, **cpu)
+            extra["cpu_baseline"]["ranks_waiting"] = world - 1
         except Exception as e:  # noqa: BLE001
             extra["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    if cpu is not None and dist is not None:
+        dist.barrier()
     return {**extra,
             "workload": "%s: %d UAV x %d PoI x %d envs job-wide = %d per GPU over %d GPU(s), random-action env-step kernel%s, "
                         "%d fused launches x %d steps, actions drawn in-kernel, obs written"
@@ -592,9 +597,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %d UAV x %d PoI x %d envs per GPU, random-action env-step HIP kernel "
-                               "only, weak scaling over GPUs (%d envs job-wide); one bench step = %d rollouts = %d fused launches "
+                               "only; `value` is WEAK scaling: %d envs on EVERY GPU (%d job-wide) -- the STRONG-scaling figure with BASELINE's 4096 "
+                               "envs fixed job-wide is this line's `c2_strong` object (N > 1 only); one bench step = %d rollouts = %d fused launches "
                                "x %d batched env steps; actions %s, obs %s" % (
-                                   shape_name, N, M, E, world * E, L, L, T,
+                                   shape_name, N, M, E, E, world * E, L, L, T,
                                    "read from HBM [T,E,N,2] f32" if actions is not None else "drawn in-kernel",
                                    "skipped" if args.no_obs else "written to HBM [T,E,N,D] f32"),
                    "n_agents": N, "n_pois": M, "envs_per_gpu": E, "global_envs": world * E,
@@ -642,8 +648,19 @@ def main():
     env.close()
     del env, out, actions
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs)
+    if not args.no_cpu_baseline:
+        # north_star: the reference-semantics CPU env timed on the host cores of the same box IN THE SAME RUN, at every N.  Rank 0
+        # times the `_cpu` twins after the timed region; in an N > 1 job the other ranks wait at the barrier (their GPUs idle,
+        # the host threads are rank 0's) and the budget is tighter (<= 10 s against ~10.5 s at N = 1).
+        if rank == 0:
+            try:
+                res["cpu_baseline"] = (cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs) if world == 1 else
+                                       cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, budget_all_s=6.0, budget_single_s=2.5))
+                res["cpu_baseline"]["ranks_waiting"] = world - 1
+            except Exception as e:  # noqa: BLE001  (the headline must survive a failing baseline)
+                res["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        if dist is not None:
+            dist.barrier()
 
     def emit():
         if rank == 0:

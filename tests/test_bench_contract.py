@@ -1,5 +1,5 @@
 """-m gpu: `bench.py` honours the driver's contract -- one JSON line with the agreed keys, the roofline object measured
-with HIP events on the launch stream, a bounded cpu_baseline leg at N = 1 -- for a short run; and two ranks sharing the GPU
+with HIP events on the launch stream, a bounded cpu_baseline leg (rank 0, at every N) -- for a short run; and two ranks sharing the GPU
 over the gloo test hook report the job-wide aggregate (weak scaling: per-GPU work fixed)."""
 import json
 import os
@@ -59,8 +59,7 @@ def test_the_drivers_exact_command_is_a_real_measurement():
     assert d["roofline"]["value_buffer"].startswith("placement-probed") and fa["launches_timed"] == 48 and 0.3 < fa["frac"] < 1.0
     assert abs(fa["frac"] - d["roofline"]["algorithmic_bytes_per_launch"] / (fa["launch_ms_avg"] * 1e-3) / 1e9 / 8000.0) < 1e-9
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e5 and "sample" in c
-    assert c["batch_envs"] == 256 and c["batch_steps"] == 150                                                 # BASELINE.md 4.2 batch
+    _check_cpu_baseline(c, 0)                                                                                # BASELINE.md 4.2 batch
     assert 10 <= c["single_thread_steps_done"] <= 150 and c["single_thread_steps_done"] % c["steps_per_call"] == 0   # bounded by time, host-speed dependent
     for leg in ("c4", "c5"):                               # bounded legs are measurements: >= 0.5 s timed, physical fraction beside the algorithmic one
         assert d[leg]["timed_region_s"] >= 0.5, (leg, d[leg]["timed_region_s"])
@@ -91,9 +90,17 @@ def test_no_flags_defaults_finish_quickly_and_match_the_driver_shape():
     assert "c3" not in d and "c4" not in d and "c5" not in d and "cpu_baseline" not in d
 
 
+def _check_cpu_baseline(c, ranks_waiting, floor=1e5):
+    """north_star: the CPU figure of the same box IN THE SAME RUN, on every line (N = 1, 2, 4, 8)"""
+    assert "error" not in c, c
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > floor and "sample" in c and c["unit"] == "agent-env-steps/s"
+    assert c["batch_envs"] == 256 and c["batch_steps"] == 150 and c["ranks_waiting"] == ranks_waiting
+
+
 def test_gpus_2_launches_itself():
     """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE re-executes under torch.distributed.run (the ranks share
-    the one GPU over the gloo test hook); n_gpus = 2, twice the envs, no cpu_baseline, c3 leg with the gradient all-reduce."""
+    the one GPU over the gloo test hook); n_gpus = 2, twice the envs, the cpu_baseline of the SAME run (rank 0 times the `_cpu`
+    twins while rank 1 waits at a barrier), c3 leg with the gradient all-reduce."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--envs", "1024", "--launches-per-step", "4",
            "--c3-iters", "1", "--ppo-epoch", "2"]
@@ -103,7 +110,9 @@ def test_gpus_2_launches_itself():
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-1000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2048 and d["config"]["envs_per_gpu"] == 1024
-    assert "cpu_baseline" not in d and d["scaling"] == "weak"
+    assert d["scaling"] == "weak" and "WEAK scaling" in d["config"]["workload"] and "c2_strong" in d["config"]["workload"]
+    _check_cpu_baseline(d["cpu_baseline"], 1)
+    _check_cpu_baseline(d["c4"]["cpu_baseline"], 1, floor=2e4)
     assert abs(d["value"] - 2 * 1024 * 8 * 4 * 150 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
     assert d["roofline"]["launches_timed"] == 8
     assert "error" not in d["c3"], d["c3"]
@@ -125,7 +134,8 @@ def test_two_ranks_under_the_drivers_launcher():
                 "127.0.0.1", "--master-port", "29533"]
     d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--envs", "1024", "--launches-per-step", "4", "--no-c3"],
              env={"DCC_BENCH_BACKEND": "gloo"}, launcher=launcher)
-    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2048 and "cpu_baseline" not in d and "c3" not in d
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2048 and "c3" not in d
+    _check_cpu_baseline(d["cpu_baseline"], 1)
 
 
 def _launch_self(n, extra, env_extra=None, timeout=1500):
@@ -153,7 +163,7 @@ def test_world_8_line_before_the_first_scale_run():
     assert r.returncode == 0, r.stderr[-2000:]
     assert d["n_gpus"] == 8 and d["config"]["envs_per_gpu"] == 512 and d["config"]["global_envs"] == 4096 and d["scaling"] == "weak"
     assert abs(d["value"] - 8 * 512 * 8 * 4 * 150 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
-    assert "cpu_baseline" not in d
+    _check_cpu_baseline(d["cpu_baseline"], 7)
     rc = d["rccl"]
     assert rc["world_size"] == 8 and rc["allreduce_ok"] and rc["allreduce_of_ones"] == 8.0
     assert sorted(x["rank"] for x in rc["ranks_seen"]) == list(range(8)) and len({x["pid"] for x in rc["ranks_seen"]}) == 8
