@@ -259,7 +259,10 @@ def _agree(dist, backend, dev, ok):
 
 def _traffic_file(key, match):
     """Offline rocprofv3 PMC traffic of a workload (profiles/rNN/traffic_<key>.json, newest round first), or (None, None)."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    import glob
+    rounds = sorted((os.path.basename(os.path.dirname(f)) for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "traffic_%s.json" % key))),
+                    reverse=True)          # whatever rounds hold one, newest first (r06 > r05 > ...)
+    for rnd in rounds:
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic_%s.json" % key)))
             if match(tj["workload"]):
