@@ -56,6 +56,17 @@ def _host_threads():
     return n
 
 
+def _test_hook(name, default=None):
+    """TEST-ONLY switches (DCC_BENCH_BACKEND, DCC_DIST_SINGLE, --test-kill-rank-at-leg): honoured only with DCC_TESTING=1 -- the one
+    gate in front of every test seam (utils/pytorch_utils.test_hook); set without it they are an error, not a silent change."""
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    if os.environ.get("DCC_TESTING") != "1":
+        raise SystemExit("%s is a test hook: it is honoured only with DCC_TESTING=1 in the environment" % name)
+    return v
+
+
 def cpu_baseline(N, M, poi, r_cover, r_comm, crs, cfs, E=256, K=150, budget_all_s=8.0, budget_single_s=2.5, label="c2"):
     """the CPU restatement THROUGH THE SAME C-ABI as the GPU path (the `_cpu` twins of
     include/dcc_env.h, oracle/dcc_env_cpu.c: dcc_env_rollout_cpu with the product's dcc_env_cfg / dcc_env_out structs, host
@@ -176,7 +187,7 @@ def mappo_iterations(args, iters, warm_iters=2):
     for _ in range(warm_iters):  # hipBLASLt heuristics, allocator, eager rollout + hipGraph capture, first replay
         one_iter()
     dist = None
-    if world > 1 or os.environ.get("DCC_DIST_SINGLE") == "1":   # the latter: a 1-rank group over RCCL on a 1-GPU box (test hook)
+    if world > 1 or _test_hook("DCC_DIST_SINGLE") == "1":   # the latter: a 1-rank group over RCCL on a 1-GPU box (test hook)
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
@@ -491,14 +502,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the env hot path has no CPU fallback")
     # DCC_BENCH_BACKEND=gloo is a test hook: several ranks may then share one GPU (rendezvous over gloo)
-    backend = os.environ.get("DCC_BENCH_BACKEND", "nccl")
+    backend = _test_hook("DCC_BENCH_BACKEND", "nccl")
     if backend == "gloo":
         os.environ.setdefault("DCC_DIST_BACKEND", "gloo")
     local_dev = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     dist = None
-    if world > 1 or os.environ.get("DCC_DIST_SINGLE") == "1":   # the latter: a 1-rank group over RCCL on a 1-GPU box (test hook)
+    if world > 1 or _test_hook("DCC_DIST_SINGLE") == "1":   # the latter: a 1-rank group over RCCL on a 1-GPU box (test hook)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
@@ -703,6 +714,8 @@ def main():
 
         threading.Thread(target=on_sigterm, daemon=True).start()
         kill = args.test_kill_rank_at_leg or ""            # TEST-ONLY flag "<rank>:<leg>": that rank exits at the start of that leg
+        if kill and os.environ.get("DCC_TESTING") != "1":
+            raise SystemExit("--test-kill-rank-at-leg is a test hook: it is honoured only with DCC_TESTING=1 in the environment")
 
         def leg(key, fn):
             current[0] = key

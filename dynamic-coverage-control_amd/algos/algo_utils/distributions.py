@@ -26,8 +26,11 @@ def set_noise_source(fn):
     """Replace the standard-normal draws of action sampling: fn(shape, dtype, device) -> tensor, None restores torch.randn.
     The reference draws from torch's global generator (torch.distributions.Normal.sample, act.py:79-84); this seam lets a
     recorded noise sequence of a reference run be replayed through this package's rollout (tests/test_learner_reference_replay.py).
-    Returns the previous source."""
+    Returns the previous source.  A TEST SEAM: installing a source needs DCC_TESTING=1 (utils/pytorch_utils.require_testing)."""
     global _noise_source
+    if fn is not None:
+        import utils.pytorch_utils as ptu
+        ptu.require_testing("distributions.set_noise_source")
     prev, _noise_source = _noise_source, fn
     return prev
 

@@ -414,7 +414,10 @@ class MAPPOTrainer:
         if structured:       # the whole batch's state features: parameter-free, computed once per iteration
             buffer.features_rows(0, buffer.episode_length)
         for _ in range(self.ppo_epoch):
-            perm = self.minibatch_perms.pop(0) if getattr(self, "minibatch_perms", None) else None
+            perm = None
+            if getattr(self, "minibatch_perms", None):        # TEST SEAM (reference fixtures): honoured only with DCC_TESTING=1
+                ptu.require_testing("MAPPOTrainer.minibatch_perms")
+                perm = self.minibatch_perms.pop(0)
             for sample in buffer.feed_forward_generator(advantages, self.num_mini_batch, dedup_critic=self.dedup_critic, perm=perm,
                                                         row_width=self.policy.actor.hidden_size):
                 vl, cgn, pl, ent, agn, imp = self.ppo_update(sample, update_actor)

@@ -60,6 +60,27 @@ def use_tuned_gemms(path=None):
     return n
 
 
+def testing_enabled():
+    """DCC_TESTING=1: the ONE gate in front of every test seam of this package (tests/conftest.py and the tools that need them
+    set it).  A production run cannot trip a seam by accident: without the gate the seams below refuse to act."""
+    return os.environ.get("DCC_TESTING") == "1"
+
+
+def require_testing(what):
+    if not testing_enabled():
+        raise RuntimeError("%s is a test seam of this package: it is honoured only with DCC_TESTING=1 in the environment" % what)
+
+
+def test_hook(name, default=None):
+    """Value of the TEST-ONLY environment switch `name` (DCC_DIST_SINGLE, DCC_DIST_BACKEND, DCC_BENCH_BACKEND, DCC_GLOO_VIA_HOST);
+    set without DCC_TESTING=1 it is an error, not a silent change of behaviour."""
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    require_testing("the environment switch %s" % name)
+    return v
+
+
 def init_distributed(backend=None):
     """One process per GPU.  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment
     (torch.distributed.run); no-op when WORLD_SIZE is 1.  Returns (rank, world_size)."""
@@ -74,7 +95,7 @@ def init_distributed(backend=None):
     if world == 1:
         os.environ.setdefault("MASTER_PORT", "29571")
     if backend is None:   # DCC_DIST_BACKEND=gloo is a test hook: the ranks may then share one GPU (gloo moves CUDA tensors)
-        backend = os.environ.get("DCC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = test_hook("DCC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         set_gpu_mode(True, int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
@@ -90,7 +111,7 @@ def single_rank_group():
     distributed code path anyway -- over backend "nccl" that runs communicator creation and each collective call site
     (all-reduce sync / async, broadcast, gather_object, barrier) through RCCL on real hardware, which is where a tensor left
     on the host or an operation the backend lacks would show."""
-    return os.environ.get("DCC_DIST_SINGLE") == "1"
+    return test_hook("DCC_DIST_SINGLE") == "1"
 
 
 def dist_active():
@@ -116,7 +137,7 @@ def _stage_through_host(t):
     HSA_ENABLE_SDMA=0 (profiles/r05/world8_ab.txt).  So on gloo the tensors are staged here; DCC_GLOO_VIA_HOST=0 restores torch's
     path (the A/B knob of tools/world8_ab.py)."""
     import torch.distributed as dist
-    return t.is_cuda and dist.get_backend() == "gloo" and os.environ.get("DCC_GLOO_VIA_HOST", "1") != "0"
+    return t.is_cuda and dist.get_backend() == "gloo" and test_hook("DCC_GLOO_VIA_HOST", "1") != "0"
 
 
 def all_reduce(t, async_op=False):

@@ -5,6 +5,8 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("DCC_TESTING", "1")      # the one gate in front of the package's test seams (utils/pytorch_utils.require_testing); inherited by subprocesses
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "dynamic-coverage-control_amd")
 GOLDEN = os.path.join(ROOT, "tests", "golden")

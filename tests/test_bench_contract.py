@@ -187,3 +187,11 @@ def test_a_rank_lost_in_a_leg_still_yields_the_headline():
     assert d["n_gpus"] == 4 and d["value"] > 0 and d["roofline"]["launches_timed"] == 8 and d["rccl"]["world_size"] == 4
     assert "error" not in d["c2_strong"]
     assert "error" in d["c4"] and all("error" in d[k] for k in ("c5", "c3") if k in d)      # nothing after the loss pretends to have run
+
+
+def test_test_hooks_need_the_testing_gate():
+    """DCC_BENCH_BACKEND / --test-kill-rank-at-leg are test hooks: without DCC_TESTING=1 bench.py refuses them (tests/test_testing_gate.py)."""
+    env = {k: v for k, v in os.environ.items() if k != "DCC_TESTING"}
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--no-c3", "--no-cpu-baseline"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300, env=dict(env, DCC_BENCH_BACKEND="gloo"))
+    assert r.returncode != 0 and "DCC_TESTING=1" in r.stderr and not r.stdout.strip()
