@@ -441,7 +441,9 @@ def rccl_proof(dist, backend, dev, rank, world, local_rank):
     except Exception:  # noqa: BLE001
         ver = None
     uu = [r["uuid"] or "%s:%s" % (r["pci_bus_id"], r["device"]) for r in seen]
-    return {"backend": {"nccl": "rccl"}.get(dist.get_backend(), dist.get_backend()), "rccl_version": ver,
+    # (the gloo TEST hook stages device tensors through the host, blocking: its collectives neither overlap compute nor compare with RCCL's)
+    via_host = dist.get_backend() == "gloo" and os.environ.get("DCC_GLOO_VIA_HOST", "1") != "0"
+    return {"backend": {"nccl": "rccl"}.get(dist.get_backend(), dist.get_backend()), "rccl_version": ver, "gloo_via_host": via_host,
             "world_size": dist.get_world_size(), "ranks_seen": seen, "distinct_devices": len(set(uu)),
             "allreduce_of_ones": float(ones[0].item()), "allreduce_ok": bool((ones == float(world)).all().item())}
 

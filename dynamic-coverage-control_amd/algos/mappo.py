@@ -334,6 +334,10 @@ class MAPPOTrainer:
         if self.num_mini_batch > 1 and not recurrent:
             return self._train_mini_batches(buffer, advantages, update_actor, info)
         chunked = self.update_chunk_steps > 0 or getattr(buffer, "compact", False) or getattr(buffer, "structured", False)
+        if chunked and recurrent:
+            # chunk_sample hands out feed-forward rows (no GRU states): a recurrent policy is updated through the recurrent generators below
+            raise ValueError("update_chunk_steps / state-only storage apply to feed-forward policies: a recurrent policy needs "
+                             "update_chunk_steps: 0, compact_obs: false, structured_input: false")
         if chunked:
             if self.update_chunk_steps <= 0:   # rows are regenerated per chunk: keep them small; features are tiny
                 self.update_chunk_steps = buffer.episode_length if getattr(buffer, "structured", False) else 10
@@ -404,8 +408,18 @@ class MAPPOTrainer:
         mb_rows = T * E * N // self.num_mini_batch
         H = self.policy.actor.hidden_size
         structured = getattr(buffer, "structured", False)
-        # structured input evaluates the first block for every agent of every touched (step, env) state (up to all of them)
-        widest = (min(T * E, mb_rows) * N * H) if structured else mb_rows * max(H, buffer.obs_dim)
+        D, S = buffer.obs_dim, buffer.share_obs_dim
+        pairs = min(T * E, mb_rows)          # (step, env) states a mini-batch can touch
+        if structured:       # the first block is evaluated for every agent of every touched state (up to all of them)
+            widest = pairs * N * H
+        else:                # per storage mode, the largest tensor SharedReplayBuffer.minibatch_rows / the two trunks materialise
+            widest = mb_rows * max(H, D)                                          # the actor's rows
+            if getattr(buffer, "decentralized", False) or not self.dedup_critic:
+                widest = max(widest, mb_rows * S)                                 # one critic input per agent row
+            elif getattr(buffer, "compact", False):
+                widest = max(widest, pairs * max(S, N * D))                       # the regenerated rows of the touched states
+            else:                                                                 # row storage, critic once per pair: ALL pairs when
+                widest = max(widest, (T * E if mb_rows * 2 >= T * E else pairs) * S)   # a mini-batch touches most of them (static shapes)
         if widest >= 2 ** 31:
             need = -(-widest // (2 ** 31 - 1))
             raise ValueError("num_mini_batch = %d leaves activations of %.2e elements per mini-batch (limit 2^31 on this stack): use "

@@ -464,6 +464,10 @@ class SharedReplayBuffer(object):
             perm = torch.randperm(batch_size, device=self.device) if self.device.type == "cuda" else torch.randperm(batch_size)
         else:
             perm = torch.as_tensor(perm).reshape(-1).long()
+            # an injected sampler must not repeat rows: the structured path scatters row gradients back with index_copy_
+            # (algo_utils/fused.select_rows), which keeps ONE contribution per index
+            if perm.numel() and int(torch.unique(perm).numel()) != perm.numel():
+                raise ValueError("feed_forward_generator: the injected row order repeats rows (sampling with replacement is not supported)")
         for i in range(num_mini_batch):
             yield self.minibatch_rows(advantages, perm[i * mini_batch_size:(i + 1) * mini_batch_size], dedup_critic, row_width)
 
@@ -482,8 +486,8 @@ class SharedReplayBuffer(object):
         return out
 
     def minibatch_rows(self, advantages, rows, dedup_critic=False, row_width=None):
-        """The reference's mini-batch for the agent rows `rows` -- indices into the (t, e, n) flattening of the T*E*N rows,
-        what `sampler` holds at shared_buffer.py:239-240 -- as its 12-tuple (:258-279).
+        """The reference's mini-batch for the agent rows `rows` -- UNIQUE indices into the (t, e, n) flattening of the T*E*N rows,
+        what `sampler` holds at shared_buffer.py:239-240 (a slice of a permutation) -- as its 12-tuple (:258-279).
         A row (t, e, n) needs agent n's observation of state (t, e) and the centralised observation of that state.  Neither is
         gathered N times over: the (step, env) pairs the rows touch are made unique (`pairs`, sorted), and
           * row storage:      obs_batch = the rows themselves; share_obs_batch = one row per touched pair (dedup_critic) or per
