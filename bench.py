@@ -236,6 +236,8 @@ def mappo_iterations(args, iters, warm_iters=2):
            "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
            "train_info": {k: float(v) for k, v in tinfo.items()}, "rollout_info": info}
     res["update_tflops_as_evaluated"] = ours_fwd * rows * 3 * args.ppo_epoch / 1e12 / (tu / iters)
+    if (N, args.pois, E, T) == (8, 64, 4096, 150) and structured:      # north_star: MFMA utilisation of the policy GEMMs against the MI355X peak
+        res["mfma"] = _mfma_file()
     lr.train_envs.close()
     del lr
     return res
@@ -281,6 +283,34 @@ def _traffic_file(key, match):
         except Exception:
             pass
     return None, None
+
+
+def _mfma_file():
+    """MFMA-pipe utilisation of the c3 iteration from the newest OFFLINE counter pass (profiles/rNN/mappo_c3_mfma_pmc.txt, written by
+    tools/pmc_mfma_c3.sh: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE, its own run), or None."""
+    import glob
+    import re
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "mappo_c3_mfma_pmc.txt")), reverse=True):
+        try:
+            gemms, summary = [], None
+            for line in open(f):
+                m = re.match(r"^(Cijk_\S+)\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+\(([0-9.]+)% of GPU-active", line)
+                if m:
+                    gemms.append({"kernel": m.group(1)[:48], "calls": int(m.group(2)), "mfma_busy": float(m.group(3)), "tflops": float(m.group(5)),
+                                  "ms_per_call": float(m.group(6)), "share_of_gpu_active": float(m.group(7)) / 100.0})
+                m = re.match(r"^all library GEMMs.*busy ([0-9.]+) of their GPU-active time; whole iteration: ([0-9.]+) \(GEMMs are ([0-9.]+)%", line)
+                if m:
+                    summary = [float(v) for v in m.groups()]
+            if gemms and summary:
+                rnd = os.path.basename(os.path.dirname(f))
+                return {"gemm_mfma_busy": summary[0], "iteration_mfma_busy": summary[1], "gemm_share_of_gpu_active": summary[2] / 100.0,
+                        "largest_gemms": gemms[:4], "peak_tflops_fp32_matrix": 157.3,
+                        "source": "offline rocprofv3 --pmc pass of `bench.py --mode mappo --iters 1 --ppo-epoch 2` (profiles/%s/mappo_c3_mfma_pmc.txt, "
+                                  "tools/pmc_mfma_c3.sh), not measured in this run; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), "
+                                  "tflops = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 / kernel time of the trace run next to it" % rnd}
+        except Exception:
+            pass
+    return None
 
 
 def env_shape_leg(N, M, E_total, world, rank, local_dev, dist, backend, T=30, launches=160, warm=3, cfs=0.0, r_comm=0.4,

@@ -82,6 +82,8 @@ def test_the_drivers_exact_command_is_a_real_measurement():
     assert "error" not in c3, c3
     assert c3["value"] > 1e6 and c3["iters_timed"] == 2 and c3["rollout_s_per_iter"] > 0 and c3["update_s_per_iter"] > 0
     assert all(v == v for v in c3["train_info"].values())        # finite losses / norms
+    mf = c3["mfma"]                                              # MFMA utilisation of the policy GEMMs (offline counter pass, source named)
+    assert mf is None or (0.0 < mf["gemm_mfma_busy"] <= 1.0 and "offline" in mf["source"] and mf["largest_gemms"][0]["tflops"] < mf["peak_tflops_fp32_matrix"])
 
 
 def test_no_flags_defaults_finish_quickly_and_match_the_driver_shape():
