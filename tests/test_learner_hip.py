@@ -369,15 +369,19 @@ def test_graph_replay_does_not_reuse_stale_features():
     ptu.set_gpu_mode(False)
 
 
-def test_hip_graph_rollout_equals_the_eager_rollout():
+@pytest.mark.parametrize("branch", [{}, {"use_centralized_V": False}, {"use_gae": False}, {"use_proper_time_limits": True},
+                                    {"use_gae": False, "use_proper_time_limits": True}],
+                         ids=["shipped", "decentralized_V", "no_gae", "proper_time_limits", "no_gae_proper_time_limits"])
+def test_hip_graph_rollout_equals_the_eager_rollout(branch):
     """use_hip_graph (default on): the captured rollout holds no reduction -- per-env reward sums / coverage maxima are
     accumulated element-wise inside the graph and reduced after the replay -- and a replay fills the buffer and returns
-    the statistics exactly like the same rollout issued eagerly from the same RNG state."""
+    the statistics exactly like the same rollout issued eagerly from the same RNG state.  Also with the configuration branches
+    served since round 6 (critic per agent row; dcc_returns_compute inside the captured body)."""
     import utils.pytorch_utils as ptu
     ptu.set_gpu_mode(True, 0)
     from learner import Learner
     kw = dict(n_rollout_threads=32, n_eval_rollout_threads=0, num_agents=4, num_pois=16, max_ep_len=12, n_iters=1,
-              ppo_epoch=2, algo_hidden_size=32, save_model=False, seed=17)
+              ppo_epoch=2, algo_hidden_size=32, save_model=False, seed=17, **branch)
     g, e = Learner(_cfg(**dict(kw, use_hip_graph=True))), Learner(_cfg(**dict(kw, use_hip_graph=False)))
     torch.manual_seed(5); g.rollout(g.rl_buffer, g.train_envs)            # eager pass + capture
     assert g.use_hip_graph and len(g._graphs) == 1, "capture must have succeeded on the GPU box"
@@ -387,8 +391,10 @@ def test_hip_graph_rollout_equals_the_eager_rollout():
         torch.cuda.set_rng_state(st)
         r_eager = e.rollout(e.rl_buffer, e.train_envs)
         assert r_replay == r_eager, it
-        for name in ("actions", "rewards", "masks", "value_preds", "returns", "state_pos"):
-            assert torch.equal(getattr(g.rl_buffer, name), getattr(e.rl_buffer, name)), (name, it)
+        for name in ("actions", "rewards", "masks", "value_preds", "returns") + (("state_pos",) if g.rl_buffer.store_state else ("obs",)):
+            assert torch.equal(torch.as_tensor(getattr(g.rl_buffer, name)), torch.as_tensor(getattr(e.rl_buffer, name))), (name, it)
+        if branch.get("use_centralized_V") is False:     # one value per AGENT row (the agents of an env see different rows)
+            assert float((g.rl_buffer.value_preds - g.rl_buffer.value_preds[:, :, :1]).abs().max()) > 0.0
         ig, ie = g.rl_update(), e.rl_update()
         assert ig == ie and all(np.isfinite(v) for v in ig.values())
     ptu.set_gpu_mode(False)
