@@ -239,6 +239,46 @@ def test_full_size_c3_iteration():
     ptu.set_gpu_mode(False)
 
 
+@pytest.mark.parametrize("branch", [{"use_centralized_V": False}, {"use_gae": False, "use_proper_time_limits": True}],
+                         ids=["decentralized_V", "no_gae_proper_time_limits"])
+def test_full_size_iteration_on_the_other_configuration_branches(branch):
+    """The configuration branches served since round 6, once at the c3 size (4096 envs x 8 UAVs x 150 steps, 1 PPO epoch):
+    `use_centralized_V: false` -- row storage, the critic on all 4.9 M agent rows, one value per agent -- and the
+    time-limit-aware discounted returns through dcc_returns_compute inside the replayed rollout graph."""
+    import yaml
+    from argparse import Namespace
+    import utils.pytorch_utils as ptu
+    ptu.set_gpu_mode(True, 0)
+    torch.cuda.empty_cache()
+    from learner import Learner
+    cfg = {}
+    for f in ("config/env_config/dcc.yaml", "config/algo_config/mappo.yaml", "config/expt.yaml"):
+        cfg.update(yaml.safe_load(open(os.path.join(PKG, f))))
+    cfg.update(num_agents=8, num_pois=64, n_rollout_threads=4096, n_eval_rollout_threads=0, ppo_epoch=1, save_model=False, n_iters=1, **branch)
+    lr = Learner(Namespace(**cfg))
+    b = lr.rl_buffer
+    for it in range(2):                      # eager + capture, then a graph replay
+        r = lr.rollout(b, lr.train_envs)
+        assert bool(torch.isfinite(b.returns).all()) and bool(torch.isfinite(b.value_preds).all())
+        assert bool(((b.masks == 0) | (b.masks == 1)).all()) and int((b.masks[1:, :, 0, 0] == 0).sum()) > 0
+        spread = float((b.value_preds[:-1] - b.value_preds[:-1, :, :1]).abs().max())
+        if branch.get("use_centralized_V") is False:
+            assert b.decentralized and not b.compact and b.share_obs is b.obs and spread > 0.0       # one value per AGENT row
+            assert lr.policy.critic.base.mlp.fc1[0].in_features == b.obs_dim
+        else:
+            assert spread == 0.0 and b.compact and b.structured
+            # returns[t] = (returns[t+1] gamma masks[t+1] + rewards[t]) with bad_masks = 1 (shared_buffer.py:190-197): checked on the last step
+            want = b.returns[-1] * cfg["gamma"] * b.masks[-1] + b.rewards[-1]
+            assert torch.allclose(b.returns[-2], want, rtol=1e-6, atol=1e-3)
+        info = lr.rl_update()
+        assert all(np.isfinite(v) for v in info.values()), info
+        assert 0.9 < info["ratio"] < 1.1 and info["critic_grad_norm"] > 0 and 0.0 <= r["coverage_rate"] <= 1.0
+    lr.train_envs.close()
+    del lr
+    torch.cuda.empty_cache()
+    ptu.set_gpu_mode(False)
+
+
 def test_full_size_c5_shard_iteration():
     """BASELINE configs[4]'s per-GPU shard through the learner: 32 UAV x 1024 PoI x 2048 envs x 150 steps with the pull
     force on = 9,830,400 agent rows.  A [rows, 256] activation of the whole batch would have 2.5e9 elements; beyond 2^31
