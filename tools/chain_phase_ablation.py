@@ -64,7 +64,7 @@ def one():
     poi = np.load(os.path.join(R, "dynamic-coverage-control_amd", "envs", "mpe", "pos_pois.npy"))[:M]
     os.environ["DCC_AUTOTUNE"] = "0"
     res = []
-    for E in (256, 512):
+    for E in [int(v) for v in os.environ.get("AB_ENVS", "256,512").split(",")]:
         for act in ("rng", "hbm"):
             env = dcc_hip.HipCoverageEnv(E, N, M, poi)
             env.reset()
