@@ -52,6 +52,8 @@ struct KParams {
     int vec_ok;                 // obs rows may be stored as float4
     int use_connect, use_force;
     int roles_envs;             // role-specialised kernel: envs per workgroup (2; 1 for small batches: twice the workgroups, half the chain)
+    int obs_drain;              // store pacing of the row-producing waves: 2 = wait for the wave's stores in flight before every staging-window
+                                // flush (default), 0 = only at the start of an env-step (role-specialised kernel), -1 = never (DCC_OBS_DRAIN, A/B)
     unsigned magicN;            // ceil(2^20 / N): p / N == (p * magicN) >> 20 for p < 4096
     double sq_cover, sq_thr, sq_thr_s, sq_speed;  // radicand bounds of the threshold tests (see kernel)
     double thr2, dmax, contact_force, contact_margin;
@@ -149,10 +151,15 @@ struct Stager {
     float* gout;   // HBM base of this env-step's obs block
     int w0;        // flat index held by stg[0] (multiple of 4 in vector mode)
     int vec;
+    int drain = 0; // 2: a flush starts only when the wave's earlier stores have been taken by the L2 (KParams::obs_drain)
 
     // Stream out [w0, end) and slide the window so that `s` (next flat index to be produced) fits.
     __device__ __forceinline__ void flush(int s, int lane) {
         wave_fence();
+        // Paced store stream: at most one window (4 KB = four 1 KB store instructions) of this wave is in flight.  Measured on
+        // MI355X (profiles/r06/obs_store_pacing.txt): c2 x 4096 envs +3.0-4.5 %, c4 / c5 shards +4.9 / +3.6 %, small batches and
+        // the 8192- / 16384-env legs unchanged; windows of 2 / 8 / 16 KB, a deeper queue (vmcnt >= 4) or non-temporal stores lose.
+        if (drain == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int end = vec ? (s & ~3) : s;
         const int n = end - w0;
         if (vec) {
@@ -163,7 +170,12 @@ struct Stager {
 #pragma unroll 4
             for (int b = 0; b < nv; b += 64) {
                 const int v = b + lane;
+#ifdef DCC_OBS_NT
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                if (v < nv) __builtin_nontemporal_store(reinterpret_cast<const v4f*>(s4)[v], reinterpret_cast<v4f*>(g4) + v);
+#else
                 if (v < nv) g4[v] = s4[v];
+#endif
             }
         } else {
             for (int v = lane; v < n; v += 64) gout[w0 + v] = stg[v];
@@ -293,13 +305,21 @@ __device__ __forceinline__ void write_step_outputs(const KParams& p, const size_
             }
         }
     }
+    // The pointers are copied to (scalar) locals first: `lane == 0 ? p.done : ...` on the struct MEMBERS is a conditional
+    // lvalue, i.e. a per-lane ADDRESS into the kernel-argument segment followed by a vector load + `s_waitcnt vmcnt(0)` --
+    // which on gfx9 also waits for every row store the wave still has in flight, once per env-step.
+    uint8_t* const d_done = p.done;
+    uint8_t* const d_connect = p.connect;
+    uint8_t* const d_connect_s = p.connect_s;
+    float* const d_reward = p.reward;
+    float* const d_coverage = p.coverage;
     if (lane < 3) {
-        uint8_t* dst = lane == 0 ? p.done : lane == 1 ? p.connect : p.connect_s;
+        uint8_t* dst = lane == 0 ? d_done : lane == 1 ? d_connect : d_connect_s;
         const bool v = lane == 0 ? env_done : lane == 1 ? connect : connect_s;
         if (dst) dst[ko] = v ? 1 : 0;
     }
     if (lane < 2) {
-        float* dst = lane == 0 ? p.reward : p.coverage;
+        float* dst = lane == 0 ? d_reward : d_coverage;
         const float v = lane == 0 ? (float)R : cov;
         if (dst) dst[ko] = v;
     }
@@ -779,7 +799,7 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? (PPL >= 4 ? 2 : 3)
         if (p.st_pos || p.st_vel || p.st_energy || p.st_done) write_step_state<PPL>(p, (size_t)k * p.E + env, lane, N, M, r);
         if (p.obs) {
             Stager st;
-            st.stg = stg; st.w0 = 0; st.vec = SPEC ? 1 : p.vec_ok;
+            st.stg = stg; st.w0 = 0; st.vec = SPEC ? 1 : p.vec_ok; st.drain = p.obs_drain;
             st.gout = p.obs + ((size_t)k * p.E + env) * (size_t)L;
             produce_obs<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(apos), r.en, r.dmask, poi, lane);
         }
@@ -1058,6 +1078,12 @@ __device__ __forceinline__ void publish(unsigned* flag, unsigned v, int lane) {
     if (lane == 0) __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Up to round 5 every env-step of the observation wave held an accidental `global_load` + `s_waitcnt vmcnt(0)`: write_step_outputs
+// selected its output pointers with `lane == 0 ? p.done : ...` on the struct MEMBERS, a conditional lvalue, i.e. a per-lane address
+// into the kernel-argument segment and a vector load from it.  The load's round trip cost 12 % at 256 envs; its full drain of
+// the store queue, on the other hand, GAINED 1.5 % at 4096 envs -- which is how the pacing of KParams::obs_drain was found.
+__device__ __forceinline__ void obs_store_queue_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int ACT, bool FORCE, int NC, int MC>
 __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1136,7 +1162,7 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
         __builtin_amdgcn_s_setprio(DCC_ROLES_OBS_PRIO);
         unsigned assign_w0 = 0;   // env 0's packed assignment row, held until env 1's is ready
         Stager st;
-        st.stg = stg; st.w0 = 0; st.vec = SPEC ? 1 : p.vec_ok; st.gout = p.obs;
+        st.stg = stg; st.w0 = 0; st.vec = SPEC ? 1 : p.vec_ok; st.gout = p.obs; st.drain = p.obs_drain;
         for (int k = 0; k < p.K; ++k) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -1144,6 +1170,7 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
                 if (env >= p.E || s >= epw) continue;
                 if (kRolesObs == 2 && s != role - 1) continue;       // one observation wave per env
                 spin_until_ge(&flags[s], (unsigned)(k + 1));
+                if (p.obs_drain == 0) obs_store_queue_drain();
                 Handoff h = handoff_at(hbase + (2 * s + (k & 1)) * hb, N);
                 float en[1];
                 en[0] = h.en[lane];
@@ -1346,7 +1373,7 @@ __global__ __launch_bounds__(kSplitBlock, (PPL >= 8 || FORCE ? 1 : 2)) void dcc_
             const unsigned dmask = h.dm[lane];
             if (i1 > i0) {
                 Stager st;
-                st.stg = stg; st.w0 = 0; st.vec = vec;
+                st.stg = stg; st.w0 = 0; st.vec = vec; st.drain = p.obs_drain;
                 st.gout = p.obs + ((size_t)k * p.E + env) * (size_t)L + (size_t)i0 * D;
                 produce_obs_rows<PPL, FORCE, NC, MC>(p, st, reinterpret_cast<const double*>(h.apos), en, dmask, poi, lane, i0, i1);
             }
@@ -1390,6 +1417,7 @@ struct dcc_env {
     bool no_spec = false, no_roles = false, force_roles = false, no_split = false, force_split = false;
     int roles_envs_forced = 0;  // DCC_ROLES_ENVS = 1 / 2 (tests, A/B); 0 = by batch size
     int roles1_max = 1024;      // batches up to this many envs run one env per role-specialised workgroup (DCC_ROLES1_MAX)
+    int obs_drain_forced = -2;  // DCC_OBS_DRAIN = -1 / 0 / 2 (A/B); -2 = the default (2)
     // create-time choice between the role-specialised and the fused kernel for obs-writing multi-step launches with one PoI
     // per lane (which of the two streams faster depends on the box: DESIGN.md 4.1); tune_us: measured us per step of each
     bool prefer_fused = false;
@@ -1498,6 +1526,7 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
     // specialised kernels assume float4-aligned obs rows; DCC_NO_SPEC=1 forces the generic kernels (tests)
     const bool allow_spec = (p.obs == nullptr || p.vec_ok) && !env->no_spec;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    p.obs_drain = (env->obs_drain_forced > -2) ? env->obs_drain_forced : 2;
     // observation-producing launches with one PoI per lane use the role-specialised kernel
     // (DCC_NO_ROLES=1 forces the fused kernel: tests, A/B)
     // and only for fused multi-step launches: with K = 1 there is nothing to pipeline and the hand-off only adds
@@ -1734,7 +1763,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     KParams& p = e->base;
     std::memset(&p, 0, sizeof(p));
     p.E = E; p.N = N; p.M = M; p.D = e->D; p.L = e->L; p.H = 4 + 2 * (N - 1);
-    p.K = 1; p.mode = 0; p.roles_envs = 2;
+    p.K = 1; p.mode = 0; p.roles_envs = 2; p.obs_drain = 2;
     p.use_connect = c->comm_r_scale > 0;
     const double contact_force = 1e+2 * c->comm_force_scale;  // core.py:109 scaled at CW:16
     p.use_force = contact_force > 0;
@@ -1760,6 +1789,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     { const char* fs = std::getenv("DCC_FORCE_SPLIT"); e->force_split = fs && fs[0] == '1'; }
     { const char* re = std::getenv("DCC_ROLES_ENVS"); if (re && (re[0] == '1' || re[0] == '2')) e->roles_envs_forced = re[0] - '0'; }
     { const char* rm = std::getenv("DCC_ROLES1_MAX"); if (rm) e->roles1_max = std::atoi(rm); }
+    { const char* od = std::getenv("DCC_OBS_DRAIN"); if (od && od[0]) e->obs_drain_forced = std::atoi(od); }
     e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kRolesObs * kStageC * 4;
     e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);
     e->lds_bytes_split = (size_t)((M * 16 + 15) & ~15) + 2 * ((size_t)N * 32 + (size_t)p2 * 256 + 256) + 32 +
