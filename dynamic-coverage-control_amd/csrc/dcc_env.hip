@@ -166,16 +166,16 @@ struct Stager {
             const int nv = n >> 2;
             const float4* s4 = reinterpret_cast<const float4*>(stg);
             float4* g4 = reinterpret_cast<float4*>(gout + w0);
-            // trip count is wave-uniform (static in the specialised kernels -> straight-line code)
-#pragma unroll 4
-            for (int b = 0; b < nv; b += 64) {
+            // Four 1 KB pieces per trip: the LDS reads are issued back to back (one LDS round trip per trip instead of one per
+            // piece -- a read past `nv` stays inside the window and is never stored), then the stores.  Trip count is wave-uniform.
+            static_assert(kStageC % 1024 == 0, "flush() reads whole groups of 4 x 64 float4 from the staging window");
+            for (int b = 0; b < nv; b += 256) {
                 const int v = b + lane;
-#ifdef DCC_OBS_NT
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                if (v < nv) __builtin_nontemporal_store(reinterpret_cast<const v4f*>(s4)[v], reinterpret_cast<v4f*>(g4) + v);
-#else
-                if (v < nv) g4[v] = s4[v];
-#endif
+                const float4 a0 = s4[v], a1 = s4[v + 64], a2 = s4[v + 128], a3 = s4[v + 192];
+                if (v < nv) g4[v] = a0;
+                if (v + 64 < nv) g4[v + 64] = a1;
+                if (v + 128 < nv) g4[v + 128] = a2;
+                if (v + 192 < nv) g4[v + 192] = a3;
             }
         } else {
             for (int v = lane; v < n; v += 64) gout[w0 + v] = stg[v];

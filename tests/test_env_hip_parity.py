@@ -558,3 +558,36 @@ def test_placed_observation_buffer_is_just_a_buffer(oracle_mod):
     small = env.alloc_out(2, placed=3)
     assert env.placement_info is None and tuple(small["obs"].shape) == (2, E, N, env.D)
     env.close()
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 66, 0.0, 0.4), (8, 64, 1500, 0.0, 0.4), (16, 256, 40, 0.5, 0.15), (5, 37, 33, 0.5, 0.2)],
+                         ids=lambda s: "n%dm%de%d" % s[:3])
+def test_store_pacing_modes_are_bit_identical(shape, monkeypatch):
+    """DCC_OBS_DRAIN (KParams::obs_drain) only moves `s_waitcnt vmcnt(0)` around in the row-producing waves -- before every
+    staging-window flush (2, the default), at the start of an env-step (0), nowhere (-1): every output of a fused rollout,
+    observation rows included, and the state it leaves are the same bits in all three, for the role-specialised (one and two
+    envs per workgroup), the split and the fused kernel shape."""
+    import dcc_hip
+    N, M, E, cfs, r_comm = shape
+    from envs.hip_vec_env import load_pois
+    poi = load_pois(M)
+    monkeypatch.setenv("DCC_AUTOTUNE", "0")
+    K, ref, ref_state = 12, None, None
+    acts = torch.rand(K, E, N, 2, device="cuda") * 2 - 1
+    for mode in ("2", "0", "-1", None):
+        if mode is None:
+            monkeypatch.delenv("DCC_OBS_DRAIN", raising=False)
+        else:
+            monkeypatch.setenv("DCC_OBS_DRAIN", mode)
+        env = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, r_comm, 0.95, cfs)
+        env.reset()
+        out = env.rollout(K, actions=acts, seed=0, step0=0, env0=0, env_total=E)
+        st = env.get_state()
+        if ref is None:
+            ref, ref_state = {k: v.clone() for k, v in out.items()}, st
+        else:
+            for k in ref:
+                assert torch.equal(out[k], ref[k]), (k, mode)
+            for k in st:
+                assert torch.equal(st[k], ref_state[k]), (k, mode)
+        env.close()
