@@ -573,7 +573,9 @@ def main():
     # ... and next to it the figure for the FIRST allocation the process gets, which is what a caller that does not probe streams
     # into (the learner's default): allocated first, timed over --first-alloc-launches launches outside the timed region
     out_first = env.alloc_out(T, obs=not args.no_obs, assign=not args.no_assign) if (args.place_tries > 0 and not args.no_obs) else None
-    out = env.alloc_out(T, obs=not args.no_obs, assign=not args.no_assign, placed=args.place_tries)
+    # (the first allocation is candidate 0 of the probe: `value` never comes from a worse-placed buffer than `first_allocation`)
+    out = env.alloc_out(T, obs=not args.no_obs, assign=not args.no_assign, placed=args.place_tries,
+                        first_obs=out_first["obs"] if out_first is not None else None)
     placement = env.placement_info
     env.reset()
     if args.no_scalars:
@@ -673,7 +675,7 @@ def main():
                        "output_placement": placement,      # untimed preparation, like the inputs: which allocation the rows go to
                        # `value` / `frac` above: the placement-probed buffer when --place-tries > 0.  The same launch into the
                        # process's FIRST allocation (what a caller that does not probe gets), timed outside the timed region:
-                       "value_buffer": "placement-probed (best of %d candidates)" % args.place_tries if args.place_tries > 0 else "first allocation",
+                       "value_buffer": "placement-probed (best of the first allocation + up to %d further candidates)" % args.place_tries if args.place_tries > 0 else "first allocation",
                        "first_allocation": ({"launch_ms_avg": first_alloc, "launches_timed": args.first_alloc_launches,
                                              "achieved": alg / (first_alloc * 1e-3) / 1e9, "frac": alg / (first_alloc * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "value_equivalent": E * N * T / (first_alloc * 1e-3) * world}

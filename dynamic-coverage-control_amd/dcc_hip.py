@@ -185,7 +185,7 @@ class HipCoverageEnv:
 
     PLACE_MIN_BYTES = 256 << 20     # buffers below this are not worth placing
 
-    def alloc_placed_obs(self, K, tries=6):
+    def alloc_placed_obs(self, K, tries=6, first=None):
         """An observation buffer [K, E, N, D] for MANY fused launches, placed well.  Where a buffer lies in HBM decides how fast
         the env kernels' store pattern streams into it: the same launch runs 6-8 % slower into some allocations than into
         others of the same process, reproducibly per buffer (tools/placement_probe.py; a sequential memset does not care, so
@@ -194,6 +194,8 @@ class HipCoverageEnv:
         part and slow in another) while the earlier ones
         stay allocated, the fastest is kept and the others go back to the allocator; stops early once a candidate is clearly in
         the fast mode (>= 4 % ahead of the slowest seen).  RESETS the env state (call before the first step).
+        `first`: a buffer of that shape the caller already holds (the process's first allocation): probed as candidate 0, so
+        that what is kept is never a worse placement than the one the caller would have used anyway.
         Returns (tensor, info) with info = {"tried", "probe_ms", "chosen"}."""
         shape = (K, self.E, self.N, self.D)
         kp = K
@@ -203,11 +205,16 @@ class HipCoverageEnv:
         cands, times = [], []
         ev = lambda: torch.cuda.Event(enable_timing=True)
         with torch.cuda.device(self.device):
-            for i in range(max(1, tries)):
-                try:
-                    t = torch.empty(shape, dtype=torch.float32, device=self.device)
-                except torch.cuda.OutOfMemoryError:
-                    break
+            if first is not None and (tuple(first.shape) != shape or first.dtype != torch.float32 or not first.is_contiguous()):
+                raise ValueError("alloc_placed_obs: `first` must be a contiguous float32 %s tensor" % (shape,))
+            for i in range(max(1, tries) + (1 if first is not None else 0)):
+                if i == 0 and first is not None:
+                    t = first
+                else:
+                    try:
+                        t = torch.empty(shape, dtype=torch.float32, device=self.device)
+                    except torch.cuda.OutOfMemoryError:
+                        break
                 best = None
                 for rep in range(4):        # rep 0 warms up (first touch)
                     a, b = ev(), ev()
@@ -225,9 +232,12 @@ class HipCoverageEnv:
         k = min(range(len(times)), key=times.__getitem__)
         keep = cands[k]
         del cands
-        return keep, {"tried": len(times), "probe_ms": [round(x, 4) for x in times], "chosen": k, "probe_steps": kp}
+        info = {"tried": len(times), "probe_ms": [round(x, 4) for x in times], "chosen": k, "probe_steps": kp}
+        if first is not None:
+            info["candidate_0"] = "the caller's first allocation"
+        return keep, info
 
-    def alloc_out(self, K=None, obs=True, assign=True, reward64=False, placed=0):
+    def alloc_out(self, K=None, obs=True, assign=True, reward64=False, placed=0, first_obs=None):
         """Output tensors of step() (K None) / rollout(K).  placed = n > 0 (rollout buffers of >= 256 MB only): the observation
         buffer is the best-placed of up to n candidate allocations (alloc_placed_obs; resets the env state) and
         `self.placement_info` says what was tried."""
@@ -238,7 +248,7 @@ class HipCoverageEnv:
                    coverage=mk((self.E,), torch.float32))
         self.placement_info = None
         if obs and placed and K and K * self.E * self.N * self.D * 4 >= self.PLACE_MIN_BYTES:
-            out["obs"], self.placement_info = self.alloc_placed_obs(K, placed)
+            out["obs"], self.placement_info = self.alloc_placed_obs(K, placed, first=first_obs)
         elif obs:
             out["obs"] = mk((self.E, self.N, self.D), torch.float32)
         if assign:
