@@ -9,17 +9,19 @@
 
 // region = [K][E] blocks of blk4 float4; writer w owns envs [w*G, (w+1)*G) and at step k streams its G adjacent blocks.
 // One writer wave per 64-thread workgroup (workgroup b runs on XCD b % 8); SWZ: the workgroups of one XCD take consecutive writers.
+// env_lo / env_n: the launch covers envs [env_lo, env_lo + env_n) of the E-env layout (part launches: `halves` below).
 template <int P, bool SWZ>
-__global__ void fill_steps(float4* p, int K, int E, int blk4, int G, float v) {
+__global__ void fill_steps(float4* p, int K, int E, int blk4, int G, float v, int env_lo = 0, int env_n = -1) {
     const int lane = threadIdx.x & 63;
     const int nb = gridDim.x * (blockDim.x >> 6);
     int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (SWZ) { const int full = nb & ~7; if (b < full) b = (b & 7) * (full >> 3) + (b >> 3); }
-    if ((size_t)(b + 1) * G > (size_t)E) return;
+    if (env_n < 0) env_n = E;
+    if ((size_t)(b + 1) * G > (size_t)env_n) return;
     const float4 x = make_float4(v, v, v, v);
     const int run4 = blk4 * G;
     for (int k = 0; k < K; ++k) {
-        float4* g = p + ((size_t)k * E + (size_t)b * G) * blk4;
+        float4* g = p + ((size_t)k * E + env_lo + (size_t)b * G) * blk4;
         int cnt = 0;
         for (int i = lane; i < run4; i += 64) {
             if (P > 0 && cnt == P) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); cnt = 0; }
@@ -48,7 +50,7 @@ double run(float4* a, int K, int E, size_t blk, int G, int wpb) {
 int main() {
     const size_t bytes = (size_t)150 * 4096 * 676 * 16;   // 6.6 GB = the c2 observation stream of one launch
     float4* a; CK(hipMalloc(&a, bytes));
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < (getenv("WP9_PARTS_ONLY") ? 0 : 2); ++rep) {
         printf("hipMemsetAsync   %6.0f GB/s\n", timeit([&] { CK(hipMemsetAsync(a, 0, bytes, 0)); }, bytes));
         printf("c2 stream (K = 150, E = 4096, 10816 B per env-step): GB/s by envs per writer G, waves per workgroup, pacing window P (0 = none), XCD-aware mapping\n");
         for (int G : {1, 2, 3, 4, 8, 16})
@@ -60,5 +62,12 @@ int main() {
                 fflush(stdout);
             }
     }
+    // the same stream as 1 / 2 / 4 part launches over env ranges, back to back (each part: all K steps of its envs)
+    for (int rep = 0; rep < 3; ++rep)
+        for (int parts : {1, 2, 4}) {
+            const int En = 4096 / parts, writers = En / 2;
+            auto go = [&] { for (int q = 0; q < parts; ++q) fill_steps<4, true><<<writers, 64>>>(a, 150, 4096, 10816 / 16, 2, 1.f, q * En, En); };
+            printf("G=2 paced P4, %d part launch(es) of %d envs: %5.0f GB/s\n", parts, En, timeit(go, (size_t)150 * 4096 * 10816));
+        }
     return 0;
 }
