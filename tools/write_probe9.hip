@@ -31,6 +31,28 @@ __global__ void fill_steps(float4* p, int K, int E, int blk4, int G, float v, in
     }
 }
 
+// Variant: every store instruction covers ONE 1 KB-aligned piece of the absolute address space (first / last piece of a run partial),
+// and the pacing wait falls on absolute AL-byte boundaries (AL = 4096: a burst never straddles a 4 KB line of the address space).
+template <int AL>
+__global__ void fill_steps_aligned(float4* p, int K, int E, int blk4, int G, float v) {
+    const int lane = threadIdx.x & 63;
+    const int nb = gridDim.x;
+    int b = blockIdx.x;
+    { const int full = nb & ~7; if (b < full) b = (b & 7) * (full >> 3) + (b >> 3); }
+    if ((size_t)(b + 1) * G > (size_t)E) return;
+    const float4 x = make_float4(v, v, v, v);
+    const long long run4 = (long long)blk4 * G;
+    for (int k = 0; k < K; ++k) {
+        const long long g0 = ((long long)k * E + (long long)b * G) * blk4;       // float4 index of the run's start
+        const long long first = g0 & ~63LL;                                       // 1 KB-aligned piece that contains it
+        for (long long q = first; q < g0 + run4; q += 64) {
+            if ((q & (AL / 16 - 1)) == 0 && q != first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const long long i = q + lane;
+            if (i >= g0 && i < g0 + run4) p[i] = x;
+        }
+    }
+}
+
 template <typename F>
 double timeit(F f, size_t bytes) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -69,5 +91,14 @@ int main() {
             auto go = [&] { for (int q = 0; q < parts; ++q) fill_steps<4, true><<<writers, 64>>>(a, 150, 4096, 10816 / 16, 2, 1.f, q * En, En); };
             printf("G=2 paced P4, %d part launch(es) of %d envs: %5.0f GB/s\n", parts, En, timeit(go, (size_t)150 * 4096 * 10816));
         }
+    for (int rep = 0; rep < 3; ++rep) {
+        const size_t used = (size_t)150 * 4096 * 10816;
+        printf("G=2: paced P4 from the run start %5.0f | 1 KB-aligned pieces, wait on absolute 2 KB %5.0f  4 KB %5.0f  8 KB %5.0f  16 KB %5.0f boundaries\n",
+               timeit([&] { fill_steps<4, true><<<2048, 64>>>(a, 150, 4096, 676, 2, 1.f); }, used),
+               timeit([&] { fill_steps_aligned<2048><<<2048, 64>>>(a, 150, 4096, 676, 2, 1.f); }, used),
+               timeit([&] { fill_steps_aligned<4096><<<2048, 64>>>(a, 150, 4096, 676, 2, 1.f); }, used),
+               timeit([&] { fill_steps_aligned<8192><<<2048, 64>>>(a, 150, 4096, 676, 2, 1.f); }, used),
+               timeit([&] { fill_steps_aligned<16384><<<2048, 64>>>(a, 150, 4096, 676, 2, 1.f); }, used));
+    }
     return 0;
 }
