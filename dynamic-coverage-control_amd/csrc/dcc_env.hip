@@ -52,6 +52,8 @@ struct KParams {
     int vec_ok;                 // obs rows may be stored as float4
     int use_connect, use_force;
     int roles_envs;             // role-specialised kernel: envs per workgroup (2; 1 for small batches: twice the workgroups, half the chain)
+    int roles_pairs;            // role-specialised kernel: (physics, observation) wave pairs per workgroup: 1, or 2 (a 4-wave workgroup: one wave per SIMD)
+    int roles_lds;              // ... and the LDS bytes of one pair
     int obs_drain;              // store pacing of the row-producing waves: 2 = wait for the wave's stores in flight before every staging-window
                                 // flush (default), 0 = only at the start of an env-step (role-specialised kernel), -1 = never (DCC_OBS_DRAIN, A/B)
     unsigned magicN;            // ceil(2^20 / N): p / N == (p * magicN) >> 20 for p < 4096
@@ -1085,16 +1087,24 @@ __device__ __forceinline__ void publish(unsigned* flag, unsigned v, int lane) {
 __device__ __forceinline__ void obs_store_queue_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int ACT, bool FORCE, int NC, int MC>
-__global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_kernel(const KParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__global__ __launch_bounds__(2 * kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
     constexpr int PPL = 1;
     constexpr bool SPEC = NC > 0;
     const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 = physics, 1 = observation
+    // A workgroup is one (physics, observation) pair of waves, or TWO independent pairs side by side (p.roles_pairs = 2): the
+    // hardware spreads the four waves of such a workgroup over the four SIMDs of its CU, whereas two 2-wave workgroups on one CU
+    // land on three SIMDs (tools/hwid_probe.hip: the second workgroup's physics wave shares a SIMD with the first one's
+    // observation wave and one SIMD stays empty) -- what a 512-workgroup launch looks like on 256 CUs.
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = (kRolesObs == 1 && p.roles_pairs == 2) ? (wave >> 1) : 0;
+    const int role = wave - pair * (1 + kRolesObs);                        // 0 = physics, 1 = observation
+    const int tid = threadIdx.x - pair * kRolesBlock;                      // thread index inside the pair
+    unsigned char* smem = smem_wg + (size_t)pair * p.roles_lds;
     const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
     const int L = N * (4 + 2 * (N - 1) + 5 * M);
-    const int epw = p.roles_envs;                                        // envs of this workgroup: 2 (adjacent), or 1
-    const int env_base = xcd_swizzle(blockIdx.x, gridDim.x) * epw;
+    const int epw = p.roles_envs;                                        // envs of this pair of waves: 2 (adjacent), or 1
+    const int env_base = (xcd_swizzle(blockIdx.x, gridDim.x) * p.roles_pairs + pair) * epw;
 
     // LDS: PoI table | hand-off [env 0..1][slot 0..1] | flags ready[2], consumed[2] | staging window
     double2* s_poi = reinterpret_cast<double2*>(smem);
@@ -1103,8 +1113,8 @@ __global__ __launch_bounds__(kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_roles_ke
     unsigned* flags = reinterpret_cast<unsigned*>(hbase + 4 * hb);
     float* stg = reinterpret_cast<float*>(hbase + 4 * hb + 16) + (role > 1 ? (role - 1) * kStageC : 0);
 
-    for (int j = threadIdx.x; j < M; j += kRolesBlock) s_poi[j] = p.poi[j];
-    if (threadIdx.x < 4) flags[threadIdx.x] = 0u;
+    for (int j = tid; j < M; j += kRolesBlock) s_poi[j] = p.poi[j];
+    if (tid < 4) flags[tid] = 0u;
     __syncthreads();
 
     PoiLane<PPL> poi;
@@ -1416,7 +1426,10 @@ struct dcc_env {
     size_t lds_bytes = 0, lds_bytes_roles = 0, lds_bytes_split = 0;
     bool no_spec = false, no_roles = false, force_roles = false, no_split = false, force_split = false;
     int roles_envs_forced = 0;  // DCC_ROLES_ENVS = 1 / 2 (tests, A/B); 0 = by batch size
-    int roles1_max = 1024;      // batches up to this many envs run one env per role-specialised workgroup (DCC_ROLES1_MAX)
+    int roles1_max = 1600;      // batches up to this many envs run one env per (physics, observation) wave pair (DCC_ROLES1_MAX); measured
+                                // crossover on MI355X between 1536 (one env per pair +7 %) and 1792 (two envs +4 %): profiles/r06/small_batch_shapes.txt
+    int n_cus = 256;            // compute units of the device (launch-shape policy only)
+    int roles_pairs_forced = 0; // DCC_ROLES_PAIRS = 1 / 2 (A/B); 0 = by batch size
     int obs_drain_forced = -2;  // DCC_OBS_DRAIN = -1 / 0 / 2 (A/B); -2 = the default (2)
     // create-time choice between the role-specialised and the fused kernel for obs-writing multi-step launches with one PoI
     // per lane (which of the two streams faster depends on the box: DESIGN.md 4.1); tune_us: measured us per step of each
@@ -1537,8 +1550,15 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
         // Small batches are latency-bound: with two envs per workgroup a 512-env launch is 256 workgroups whose physics wave walks
         // two envs per step; one env per workgroup fills every CU twice over and halves the dependent chain of a step.
         p.roles_envs = (env->roles_envs_forced > 0) ? env->roles_envs_forced : (p.E <= env->roles1_max ? 1 : 2);
-        const int grid = (p.E + p.roles_envs - 1) / p.roles_envs;
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(kRolesBlock), env->lds_bytes_roles, s, p);
+        const int n_pairs = (p.E + p.roles_envs - 1) / p.roles_envs;
+        // Two wave pairs per workgroup where the one-pair form would put 2-3 workgroups on a CU: the dispatcher spreads a 4-wave
+        // workgroup over the four SIMDs, but packs two 2-wave workgroups onto three of them (tools/hwid_probe.hip) -- 512 envs
+        // 1.78 -> 1.62 us per step; at <= one workgroup per CU and from four per CU on the one-pair form is as good or better.
+        const bool two_pairs = p.roles_envs == 1 && n_pairs > env->n_cus && n_pairs < 4 * env->n_cus;
+        p.roles_pairs = (kRolesObs == 1) ? ((env->roles_pairs_forced > 0) ? env->roles_pairs_forced : (two_pairs ? 2 : 1)) : 1;
+        p.roles_lds = (int)env->lds_bytes_roles;
+        const int grid = (n_pairs + p.roles_pairs - 1) / p.roles_pairs;
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(kRolesBlock * p.roles_pairs), env->lds_bytes_roles * p.roles_pairs, s, p);
         HIP_TRY(hipGetLastError());
         return DCC_OK;
     }
@@ -1753,6 +1773,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     e->cfg = *c;
     e->cfg.poi_xy = nullptr;
     e->device = dev;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) e->n_cus = cus; else (void)hipGetLastError(); }
     const int E = c->n_envs, N = c->n_agents, M = c->n_pois;
     e->D = 4 + 2 * (N - 1) + 5 * M;
     e->L = N * e->D;
@@ -1763,7 +1784,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     KParams& p = e->base;
     std::memset(&p, 0, sizeof(p));
     p.E = E; p.N = N; p.M = M; p.D = e->D; p.L = e->L; p.H = 4 + 2 * (N - 1);
-    p.K = 1; p.mode = 0; p.roles_envs = 2; p.obs_drain = 2;
+    p.K = 1; p.mode = 0; p.roles_envs = 2; p.roles_pairs = 1; p.roles_lds = 0; p.obs_drain = 2;
     p.use_connect = c->comm_r_scale > 0;
     const double contact_force = 1e+2 * c->comm_force_scale;  // core.py:109 scaled at CW:16
     p.use_force = contact_force > 0;
@@ -1789,6 +1810,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     { const char* fs = std::getenv("DCC_FORCE_SPLIT"); e->force_split = fs && fs[0] == '1'; }
     { const char* re = std::getenv("DCC_ROLES_ENVS"); if (re && (re[0] == '1' || re[0] == '2')) e->roles_envs_forced = re[0] - '0'; }
     { const char* rm = std::getenv("DCC_ROLES1_MAX"); if (rm) e->roles1_max = std::atoi(rm); }
+    { const char* rp = std::getenv("DCC_ROLES_PAIRS"); if (rp && (rp[0] == '1' || rp[0] == '2')) e->roles_pairs_forced = rp[0] - '0'; }
     { const char* od = std::getenv("DCC_OBS_DRAIN"); if (od && od[0]) e->obs_drain_forced = std::atoi(od); }
     e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kRolesObs * kStageC * 4;
     e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);

@@ -591,3 +591,41 @@ def test_store_pacing_modes_are_bit_identical(shape, monkeypatch):
             for k in st:
                 assert torch.equal(st[k], ref_state[k]), (k, mode)
         env.close()
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 33, 0.0, 0.4), (8, 64, 513, 0.0, 0.4), (8, 64, 600, 0.0, 0.4), (5, 37, 65, 0.5, 0.2), (4, 20, 300, 0.0, 0.4)],
+                         ids=lambda s: "n%dm%de%d" % s[:3])
+@pytest.mark.parametrize("epw", [1, 2])
+def test_two_wave_pairs_per_workgroup_are_bit_identical(shape, epw, monkeypatch):
+    """KParams::roles_pairs = 2 (DCC_ROLES_PAIRS; chosen by launch() for batches that would put two or three one-pair workgroups
+    on a CU) runs two independent (physics, observation) wave pairs in one 4-wave workgroup, each with its own LDS region and
+    envs: same bits as the one-pair form in every output and in the state left behind, with one and two envs per pair, an odd
+    number of pairs (the last workgroup's second pair has no env) and compile-time / runtime sizes; and the default policy equals both."""
+    import dcc_hip
+    N, M, E, cfs, r_comm = shape
+    from envs.hip_vec_env import load_pois
+    poi = load_pois(M)
+    monkeypatch.setenv("DCC_AUTOTUNE", "0")
+    monkeypatch.setenv("DCC_ROLES_ENVS", str(epw))
+    K, ref, ref_state = 12, None, None
+    acts = torch.rand(K, E, N, 2, device="cuda") * 2 - 1
+    for pairs in ("1", "2", None):
+        if pairs is None:
+            monkeypatch.delenv("DCC_ROLES_PAIRS", raising=False)
+            monkeypatch.delenv("DCC_ROLES_ENVS", raising=False)
+        else:
+            monkeypatch.setenv("DCC_ROLES_PAIRS", pairs)
+        env = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, r_comm, 0.95, cfs)
+        env.reset()
+        out = env.rollout(K, actions=acts, seed=0, step0=0, env0=0, env_total=E)
+        out2 = env.rollout(K, seed=7, step0=K, env0=0, env_total=E)          # in-kernel action stream, continuing
+        st = env.get_state()
+        got = {**{k: v.clone() for k, v in out.items()}, **{"rng_" + k: v.clone() for k, v in out2.items()}}
+        if ref is None:
+            ref, ref_state = got, st
+        else:
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), (k, pairs)
+            for k in st:
+                assert torch.equal(st[k], ref_state[k]), (k, pairs)
+        env.close()

@@ -10,6 +10,7 @@ N, M, T = 8, 64, 150
 CFS, RCOMM = 0.0, 0.4
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 os.environ["DCC_AUTOTUNE"] = "0"
+VAR = os.environ.get("SWEEP_ENVVAR", "DCC_OBS_DRAIN")      # which library knob the columns vary (e.g. DCC_ROLES_PAIRS)
 DR = tuple(int(v) for v in os.environ.get("SWEEP_MODES", "-1,0,2,5").split(","))
 
 
@@ -31,7 +32,7 @@ def case(E, epw, hbm):
     os.environ["DCC_ROLES_ENVS"] = str(epw)
     envs, out = {}, None
     for d in DR:
-        os.environ["DCC_OBS_DRAIN"] = str(d)
+        os.environ[VAR] = str(d)
         envs[d] = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, RCOMM, 0.95, CFS); envs[d].reset()
         if out is None:
             out = envs[d].alloc_out(T, placed=(6 if E >= 4096 else 0))
@@ -52,7 +53,14 @@ def case(E, epw, hbm):
 
 
 SHAPE = os.environ.get("SWEEP_SHAPE", "c2")
-if SHAPE == "c4":
+if SHAPE == "mid":
+    for E in (1152, 1280, 1536, 1792, 2048, 2304):
+        for epw in (1, 2):
+            case(E, epw, False)
+elif SHAPE == "small":
+    for E in (288, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1280, 1536):
+        case(E, 1 if E <= 1024 else 2, False)
+elif SHAPE == "c4":
     N, M, T = 16, 256, 30
     for E in (1024, 8192):
         case(E, 2, False)
@@ -61,5 +69,5 @@ elif SHAPE == "c5":
     for E in (2048, 16384):
         case(E, 2, False)
 elif SHAPE == "c2":
-    for E, epw, hbm in ((512, 1, False), (1024, 1, False), (2048, 2, False), (2048, 2, True), (4096, 2, False), (4096, 2, True), (4096, 2, True)):
+    for E, epw, hbm in ((256, 1, False), (512, 1, False), (512, 1, True), (1024, 1, False), (1024, 2, False), (2048, 1, False), (2048, 2, False), (2048, 2, True), (4096, 2, False), (4096, 2, True)):
         case(E, epw, hbm)
