@@ -4,11 +4,13 @@ usage: python tools/variant_sweep.py "<modes, comma separated>" [rounds] [E ...]
 import glob, importlib.util, os, sys
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); PKG = R + "/dynamic-coverage-control_amd"; sys.path.insert(0, PKG)
 import numpy as np, torch
-N, M, T = 8, 64, 150
+N, M, T = (int(v) for v in os.environ.get("SWEEP_NMT", "8,64,150").split(","))      # e.g. SWEEP_NMT=32,1024,4 SWEEP_FORCE=0.5,0.1 for the c5 shapes
+CFS, RCOMM = (float(v) for v in os.environ.get("SWEEP_FORCE", "0.0,0.4").split(","))
 modes = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [-1, 2]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 Es = [int(v) for v in sys.argv[3:]] or [4096]
-poi = np.load(PKG + "/envs/mpe/pos_pois.npy")[:M]
+from envs.hip_vec_env import load_pois
+poi = load_pois(M)
 os.environ["DCC_AUTOTUNE"] = "0"
 libs = {}
 for so in sorted(glob.glob(PKG + "/csrc/variants/*.so")):
@@ -33,18 +35,18 @@ def timed(fn, n=12):
 
 
 for E in Es:
-    for hbm in (False, True):
+    for hbm in ((False, True) if (N, M) == (8, 64) else (False,)):
         envs, out = {}, None
         for name, mod in libs.items():
             for d in modes:
                 os.environ["DCC_OBS_DRAIN"] = str(d)
                 try:
-                    e = mod.HipCoverageEnv(E, N, M, poi); e.reset()
+                    e = mod.HipCoverageEnv(E, N, M, poi, 0.2, RCOMM, 0.95, CFS); e.reset()
                 except Exception as ex:  # noqa: BLE001
                     print("  (%s mode %d: %s)" % (name, d, str(ex)[:100])); continue
                 envs[(name, d)] = e
                 if out is None:
-                    out = e.alloc_out(T, placed=(6 if E == 4096 else 0))
+                    out = e.alloc_out(T, placed=(6 if E * N * M >= 4096 * 512 else 0))
         acts = (torch.rand(T, E, N, 2, device="cuda") * 2 - 1) if hbm else None
         res = {k: [] for k in envs}
         for r in range(rounds):
