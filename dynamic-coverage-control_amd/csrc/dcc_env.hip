@@ -54,6 +54,7 @@ struct KParams {
     int roles_envs;             // role-specialised kernel: envs per workgroup (2; 1 for small batches: twice the workgroups, half the chain)
     int roles_pairs;            // role-specialised kernel: (physics, observation) wave pairs per workgroup: 1, or 2 (a 4-wave workgroup: one wave per SIMD)
     int roles_lds;              // ... and the LDS bytes of one pair
+    int roles_slots;            // hand-off slots per env (a power of two): the physics wave may run that many steps ahead of the observation wave
     int obs_drain;              // store pacing of the row-producing waves: 2 = wait for the wave's stores in flight before every staging-window
                                 // flush (default), 0 = only at the start of an env-step (role-specialised kernel), -1 = never (DCC_OBS_DRAIN, A/B)
     unsigned magicN;            // ceil(2^20 / N): p / N == (p * magicN) >> 20 for p < 4096
@@ -1050,7 +1051,7 @@ __global__ __launch_bounds__(kBlock, (PPL >= 8 ? 2 : (FORCE ? (PPL >= 4 ? 2 : 3)
 // stores, the compute overlaps only ~2/3 with the chip-wide store stream; waves that do nothing but stream
 // stores keep HBM saturated while other waves compute in their shadow.  Here a workgroup is two waves serving
 // two envs: wave 0 runs the physics of both envs and hands the post-step state (positions, velocities, PoI
-// energies, done mask: ~0.5 KB) to wave 1 through a double-buffered LDS slot; wave 1 expands it into the
+// energies, done mask: ~0.5 KB) to wave 1 through a ring of LDS slots (KParams::roles_slots); wave 1 expands it into the
 // observation rows and streams them to HBM.  ready/consumed counters in LDS (workgroup-scope release/acquire)
 // let the physics wave run up to two steps ahead, so the observation wave always has a backlog.
 #ifndef DCC_ROLES_OBS
@@ -1104,14 +1105,15 @@ __global__ __launch_bounds__(2 * kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_role
     const int N = SPEC ? NC : p.N, M = SPEC ? MC : p.M;
     const int L = N * (4 + 2 * (N - 1) + 5 * M);
     const int epw = p.roles_envs;                                        // envs of this pair of waves: 2 (adjacent), or 1
+    const int kSlots = p.roles_slots;
     const int env_base = (xcd_swizzle(blockIdx.x, gridDim.x) * p.roles_pairs + pair) * epw;
 
     // LDS: PoI table | hand-off [env 0..1][slot 0..1] | flags ready[2], consumed[2] | staging window
     double2* s_poi = reinterpret_cast<double2*>(smem);
     const int hb = handoff_bytes(N);
     unsigned char* hbase = smem + ((M * 16 + 15) & ~15);
-    unsigned* flags = reinterpret_cast<unsigned*>(hbase + 4 * hb);
-    float* stg = reinterpret_cast<float*>(hbase + 4 * hb + 16) + (role > 1 ? (role - 1) * kStageC : 0);
+    unsigned* flags = reinterpret_cast<unsigned*>(hbase + 2 * kSlots * hb);
+    float* stg = reinterpret_cast<float*>(hbase + 2 * kSlots * hb + 16) + (role > 1 ? (role - 1) * kStageC : 0);
 
     for (int j = tid; j < M; j += kRolesBlock) s_poi[j] = p.poi[j];
     if (tid < 4) flags[tid] = 0u;
@@ -1134,7 +1136,7 @@ __global__ __launch_bounds__(2 * kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_role
             if (env < p.E && s < epw) {
                 load_env_state<PPL>(p, env, lane, N, M, r[s]);
                 // the "previous" slot (1) holds the pre-move positions of step 0
-                Handoff h = handoff_at(hbase + (2 * s + 1) * hb, N);
+                Handoff h = handoff_at(hbase + (kSlots * s + kSlots - 1) * hb, N);
                 if (lane < N) { h.apos[lane] = make_double2(r[s].px, r[s].py); h.avel[lane] = make_double2(r[s].vx, r[s].vy); }
             }
         }
@@ -1144,11 +1146,11 @@ __global__ __launch_bounds__(2 * kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_role
             for (int s = 0; s < 2; ++s) {
                 const int env = env_base + s;
                 if (env >= p.E || s >= epw) continue;
-                const int slot = k & 1;
-                Handoff out = handoff_at(hbase + (2 * s + slot) * hb, N);
-                Handoff in = handoff_at(hbase + (2 * s + (slot ^ 1)) * hb, N);
-                // slot `slot` was published at step k-2: wait until the observation wave has read it
-                if (k >= 2) spin_until_ge(&flags[2 + s], (unsigned)(k - 1));
+                const int slot = k & (kSlots - 1);
+                Handoff out = handoff_at(hbase + (kSlots * s + slot) * hb, N);
+                Handoff in = handoff_at(hbase + (kSlots * s + ((slot + kSlots - 1) & (kSlots - 1))) * hb, N);
+                // slot `slot` was published at step k - kSlots: wait until the observation wave has read it
+                if (k >= kSlots) spin_until_ge(&flags[2 + s], (unsigned)(k - kSlots + 1));
                 if (p.mode == 0) {
                     env_physics_step<PPL, ACT, FORCE, NC, MC>(p, env, k, lane, r[s], af[s], poi, in.apos, out.apos, out.avel, out.rec);
                 } else if (lane < N) {
@@ -1181,7 +1183,7 @@ __global__ __launch_bounds__(2 * kRolesBlock, (FORCE ? 3 : 4)) void dcc_env_role
                 if (kRolesObs == 2 && s != role - 1) continue;       // one observation wave per env
                 spin_until_ge(&flags[s], (unsigned)(k + 1));
                 if (p.obs_drain == 0) obs_store_queue_drain();
-                Handoff h = handoff_at(hbase + (2 * s + (k & 1)) * hb, N);
+                Handoff h = handoff_at(hbase + (kSlots * s + (k & (kSlots - 1))) * hb, N);
                 float en[1];
                 en[0] = h.en[lane];
                 const unsigned dmask = (unsigned)((*h.dmask >> lane) & 1ULL);
@@ -1429,6 +1431,7 @@ struct dcc_env {
     int roles1_max = 1600;      // batches up to this many envs run one env per (physics, observation) wave pair (DCC_ROLES1_MAX); measured
                                 // crossover on MI355X between 1536 (one env per pair +7 %) and 1792 (two envs +4 %): profiles/r06/small_batch_shapes.txt
     int n_cus = 256;            // compute units of the device (launch-shape policy only)
+    int roles_slots = 2;        // hand-off slots per env of the role-specialised kernel (DCC_ROLES_SLOTS = 2 / 4 / 8: A/B)
     int roles_pairs_forced = 0; // DCC_ROLES_PAIRS = 1 / 2 (A/B); 0 = by batch size
     int obs_drain_forced = -2;  // DCC_OBS_DRAIN = -1 / 0 / 2 (A/B); -2 = the default (2)
     // create-time choice between the role-specialised and the fused kernel for obs-writing multi-step launches with one PoI
@@ -1557,6 +1560,7 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
         const bool two_pairs = p.roles_envs == 1 && n_pairs > env->n_cus && n_pairs < 4 * env->n_cus;
         p.roles_pairs = (kRolesObs == 1) ? ((env->roles_pairs_forced > 0) ? env->roles_pairs_forced : (two_pairs ? 2 : 1)) : 1;
         p.roles_lds = (int)env->lds_bytes_roles;
+        p.roles_slots = env->roles_slots;
         const int grid = (n_pairs + p.roles_pairs - 1) / p.roles_pairs;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kRolesBlock * p.roles_pairs), env->lds_bytes_roles * p.roles_pairs, s, p);
         HIP_TRY(hipGetLastError());
@@ -1784,7 +1788,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     KParams& p = e->base;
     std::memset(&p, 0, sizeof(p));
     p.E = E; p.N = N; p.M = M; p.D = e->D; p.L = e->L; p.H = 4 + 2 * (N - 1);
-    p.K = 1; p.mode = 0; p.roles_envs = 2; p.roles_pairs = 1; p.roles_lds = 0; p.obs_drain = 2;
+    p.K = 1; p.mode = 0; p.roles_envs = 2; p.roles_pairs = 1; p.roles_lds = 0; p.roles_slots = 2; p.obs_drain = 2;
     p.use_connect = c->comm_r_scale > 0;
     const double contact_force = 1e+2 * c->comm_force_scale;  // core.py:109 scaled at CW:16
     p.use_force = contact_force > 0;
@@ -1812,7 +1816,10 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     { const char* rm = std::getenv("DCC_ROLES1_MAX"); if (rm) e->roles1_max = std::atoi(rm); }
     { const char* rp = std::getenv("DCC_ROLES_PAIRS"); if (rp && (rp[0] == '1' || rp[0] == '2')) e->roles_pairs_forced = rp[0] - '0'; }
     { const char* od = std::getenv("DCC_OBS_DRAIN"); if (od && od[0]) e->obs_drain_forced = std::atoi(od); }
-    e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 4 * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kRolesObs * kStageC * 4;
+    // hand-off depth: 8 slots per env while they are small (N <= 16: <= 1.1 KB each), else the minimum of 2.  Measured at c2 (profiles/r06/
+    // small_batch_shapes.txt): 2 -> 4 -> 8 slots = 0.793 -> 0.799 -> 0.802 of 8 TB/s at 4096 envs (HBM actions 0.732 -> 0.737 -> 0.739), no effect below 1024 envs
+    { const char* sl = std::getenv("DCC_ROLES_SLOTS"); const int v = sl ? std::atoi(sl) : 0; e->roles_slots = (v == 2 || v == 4 || v == 8) ? v : (N <= 16 ? 8 : 2); }
+    e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 2 * (size_t)e->roles_slots * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kRolesObs * kStageC * 4;
     e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);
     e->lds_bytes_split = (size_t)((M * 16 + 15) & ~15) + 2 * ((size_t)N * 32 + (size_t)p2 * 256 + 256) + 32 +
                          (size_t)kSplitObs * kStageC * 4;

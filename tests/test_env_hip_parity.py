@@ -609,12 +609,13 @@ def test_two_wave_pairs_per_workgroup_are_bit_identical(shape, epw, monkeypatch)
     monkeypatch.setenv("DCC_ROLES_ENVS", str(epw))
     K, ref, ref_state = 12, None, None
     acts = torch.rand(K, E, N, 2, device="cuda") * 2 - 1
-    for pairs in ("1", "2", None):
+    for pairs, slots in (("1", "2"), ("2", "2"), ("1", "8"), ("2", "4"), (None, None)):   # + the hand-off ring depth (KParams::roles_slots)
         if pairs is None:
-            monkeypatch.delenv("DCC_ROLES_PAIRS", raising=False)
-            monkeypatch.delenv("DCC_ROLES_ENVS", raising=False)
+            for k in ("DCC_ROLES_PAIRS", "DCC_ROLES_ENVS", "DCC_ROLES_SLOTS"):
+                monkeypatch.delenv(k, raising=False)
         else:
             monkeypatch.setenv("DCC_ROLES_PAIRS", pairs)
+            monkeypatch.setenv("DCC_ROLES_SLOTS", slots)
         env = dcc_hip.HipCoverageEnv(E, N, M, poi, 0.2, r_comm, 0.95, cfs)
         env.reset()
         out = env.rollout(K, actions=acts, seed=0, step0=0, env0=0, env_total=E)
@@ -625,7 +626,7 @@ def test_two_wave_pairs_per_workgroup_are_bit_identical(shape, epw, monkeypatch)
             ref, ref_state = got, st
         else:
             for k in ref:
-                assert torch.equal(got[k], ref[k]), (k, pairs)
+                assert torch.equal(got[k], ref[k]), (k, pairs, slots)
             for k in st:
-                assert torch.equal(st[k], ref_state[k]), (k, pairs)
+                assert torch.equal(st[k], ref_state[k]), (k, pairs, slots)
         env.close()

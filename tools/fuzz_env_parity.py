@@ -34,6 +34,7 @@ while time.time() - t0 < budget:
     crs = float(rs.choice([0.95, 0.9, rs.uniform(0.5, 1.0)]))
     form = {k: str(int(rs.rand() < 0.5)) for k in ("DCC_NO_SPEC", "DCC_NO_ROLES", "DCC_FORCE_ROLES", "DCC_NO_SPLIT", "DCC_FORCE_SPLIT")}
     form["DCC_ROLES_ENVS"] = str(int(rs.choice([1, 2])))        # envs per role-specialised workgroup
+    form["DCC_ROLES_SLOTS"] = str(int(rs.choice([2, 4, 8])))    # hand-off slots per env of the role-specialised kernel
     form["DCC_ROLES_PAIRS"] = str(int(rs.choice([1, 2])))       # (physics, observation) wave pairs per role-specialised workgroup
     os.environ.update(form)
     poi = rs.uniform(-1, 1, (M, 2))
