@@ -54,7 +54,6 @@ struct KParams {
     int roles_envs;             // role-specialised kernel: envs per workgroup (2; 1 for small batches: twice the workgroups, half the chain)
     int roles_pairs;            // role-specialised kernel: (physics, observation) wave pairs per workgroup: 1, or 2 (a 4-wave workgroup: one wave per SIMD)
     int roles_lds;              // ... and the LDS bytes of one pair
-    int split_slots;            // split kernel: hand-off slots of its env (a power of two)
     int roles_slots;            // hand-off slots per env (a power of two): the physics wave may run that many steps ahead of the observation wave
     int obs_drain;              // store pacing of the row-producing waves: 2 = wait for the wave's stores in flight before every staging-window
                                 // flush (default), 0 = only at the start of an env-step (role-specialised kernel), -1 = never (DCC_OBS_DRAIN, A/B)
@@ -1319,9 +1318,8 @@ __global__ __launch_bounds__(kSplitBlock, (PPL >= 8 || FORCE ? 1 : 2)) void dcc_
     double2* s_poi = reinterpret_cast<double2*>(smem);
     const int sb = split_slot_bytes(N, PPL);
     unsigned char* hbase = smem + ((M * 16 + 15) & ~15);
-    unsigned* flags = reinterpret_cast<unsigned*>(hbase + p.split_slots * sb);     // ready, consumed[kSplitObs] (<= 8 words)
-    const int nslots = p.split_slots;
-    float* stg_base = reinterpret_cast<float*>(hbase + nslots * sb + 32);
+    unsigned* flags = reinterpret_cast<unsigned*>(hbase + 2 * sb);                 // ready, consumed[kSplitObs] (<= 8 words)
+    float* stg_base = reinterpret_cast<float*>(hbase + 2 * sb + 32);
 
     for (int j = threadIdx.x; j < M; j += kSplitBlock) s_poi[j] = p.poi[j];
     if (threadIdx.x < 8) flags[threadIdx.x] = 0u;
@@ -1342,17 +1340,17 @@ __global__ __launch_bounds__(kSplitBlock, (PPL >= 8 || FORCE ? 1 : 2)) void dcc_
         init_act(af);
         load_env_state<PPL>(p, env, lane, N, M, r);
         {   // the "previous" slot (1) holds the pre-move positions of step 0
-            SplitSlot h = split_slot_at(hbase + (nslots - 1) * sb, N, PPL);
+            SplitSlot h = split_slot_at(hbase + sb, N, PPL);
             if (lane < N) { h.apos[lane] = make_double2(r.px, r.py); h.avel[lane] = make_double2(r.vx, r.vy); }
         }
         wave_fence();
         for (int k = 0; k < p.K; ++k) {
-            const int slot = k & (nslots - 1);
+            const int slot = k & 1;
             SplitSlot out = split_slot_at(hbase + slot * sb, N, PPL);
-            SplitSlot in = split_slot_at(hbase + ((slot + nslots - 1) & (nslots - 1)) * sb, N, PPL);
-            if (k >= nslots) {   // slot `slot` was published at step k - nslots: every observation wave must have read it
+            SplitSlot in = split_slot_at(hbase + (slot ^ 1) * sb, N, PPL);
+            if (k >= 2) {   // slot `slot` was published at step k-2: every observation wave must have read it
 #pragma unroll
-                for (int w = 0; w < kSplitObs; ++w) spin_until_ge(&flags[1 + w], (unsigned)(k - nslots + 1));
+                for (int w = 0; w < kSplitObs; ++w) spin_until_ge(&flags[1 + w], (unsigned)(k - 1));
             }
             if (p.mode == 0) {
                 env_physics_step<PPL, ACT, FORCE, NC, MC>(p, env, k, lane, r, af, poi, in.apos, out.apos, out.avel);
@@ -1380,7 +1378,7 @@ __global__ __launch_bounds__(kSplitBlock, (PPL >= 8 || FORCE ? 1 : 2)) void dcc_
         float* stg = stg_base + w * kStageC;
         for (int k = 0; k < p.K; ++k) {
             spin_until_ge(&flags[0], (unsigned)(k + 1));
-            SplitSlot h = split_slot_at(hbase + (k & (nslots - 1)) * sb, N, PPL);
+            SplitSlot h = split_slot_at(hbase + (k & 1) * sb, N, PPL);
             float en[PPL];
 #pragma unroll
             for (int q = 0; q < PPL; ++q) en[q] = h.en[q * 64 + lane];
@@ -1433,7 +1431,6 @@ struct dcc_env {
     int roles1_max = 1600;      // batches up to this many envs run one env per (physics, observation) wave pair (DCC_ROLES1_MAX); measured
                                 // crossover on MI355X between 1536 (one env per pair +7 %) and 1792 (two envs +4 %): profiles/r06/small_batch_shapes.txt
     int n_cus = 256;            // compute units of the device (launch-shape policy only)
-    int split_slots = 2;        // ... and of the split kernel (DCC_SPLIT_SLOTS)
     int roles_slots = 2;        // hand-off slots per env of the role-specialised kernel (DCC_ROLES_SLOTS = 2 / 4 / 8: A/B)
     int roles_pairs_forced = 0; // DCC_ROLES_PAIRS = 1 / 2 (A/B); 0 = by batch size
     int obs_drain_forced = -2;  // DCC_OBS_DRAIN = -1 / 0 / 2 (A/B); -2 = the default (2)
@@ -1581,7 +1578,6 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
     if (p.obs != nullptr && env->PPL > 1 && act != 1 && (p.mode == 0 || p.K >= 2) && !env->no_split &&
         ((p.E <= kSplitMaxEnvs && split_pays) || env->force_split)) {   // single steps too: 24.8 -> 22.2 us at the c4 shard
         kernel_fn fn = pick_split_kernel(env->PPL, act, p.use_force != 0, p.N, p.M, allow_spec);
-        p.split_slots = env->split_slots;
         hipLaunchKernelGGL(fn, dim3(p.E), dim3(kSplitBlock), env->lds_bytes_split, s, p);
         HIP_TRY(hipGetLastError());
         return DCC_OK;
@@ -1792,7 +1788,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     KParams& p = e->base;
     std::memset(&p, 0, sizeof(p));
     p.E = E; p.N = N; p.M = M; p.D = e->D; p.L = e->L; p.H = 4 + 2 * (N - 1);
-    p.K = 1; p.mode = 0; p.roles_envs = 2; p.roles_pairs = 1; p.roles_lds = 0; p.roles_slots = 2; p.split_slots = 2; p.obs_drain = 2;
+    p.K = 1; p.mode = 0; p.roles_envs = 2; p.roles_pairs = 1; p.roles_lds = 0; p.roles_slots = 2; p.obs_drain = 2;
     p.use_connect = c->comm_r_scale > 0;
     const double contact_force = 1e+2 * c->comm_force_scale;  // core.py:109 scaled at CW:16
     p.use_force = contact_force > 0;
@@ -1825,8 +1821,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     { const char* sl = std::getenv("DCC_ROLES_SLOTS"); const int v = sl ? std::atoi(sl) : 0; e->roles_slots = (v == 2 || v == 4 || v == 8) ? v : (N <= 16 ? 8 : 2); }
     e->lds_bytes_roles = (size_t)((M * 16 + 15) & ~15) + 2 * (size_t)e->roles_slots * ((size_t)N * 32 + 64 * 4 + 16 + sizeof(StepRec)) + 16 + (size_t)kRolesObs * kStageC * 4;
     e->lds_bytes = (size_t)((M * 16 + 15) & ~15) + (size_t)kWavesPerBlock * ((size_t)N * 32 + (size_t)kStageC * 4);
-    { const char* sl = std::getenv("DCC_SPLIT_SLOTS"); const int v = sl ? std::atoi(sl) : 0; e->split_slots = (v == 2 || v == 4 || v == 8) ? v : 2; }
-    e->lds_bytes_split = (size_t)((M * 16 + 15) & ~15) + (size_t)e->split_slots * ((size_t)N * 32 + (size_t)p2 * 256 + 256) + 32 +
+    e->lds_bytes_split = (size_t)((M * 16 + 15) & ~15) + 2 * ((size_t)N * 32 + (size_t)p2 * 256 + 256) + 32 +
                          (size_t)kSplitObs * kStageC * 4;
 
     auto cleanup = [&](int code, const std::string& m) { dcc_env_destroy(e); return fail(code, m); };
