@@ -1431,6 +1431,7 @@ struct dcc_env {
     int roles1_max = 1600;      // batches up to this many envs run one env per (physics, observation) wave pair (DCC_ROLES1_MAX); measured
                                 // crossover on MI355X between 1536 (one env per pair +7 %) and 1792 (two envs +4 %): profiles/r06/small_batch_shapes.txt
     int n_cus = 256;            // compute units of the device (launch-shape policy only)
+    size_t fused_lds_pad = 0;   // experiment (DCC_FUSED_LDS_PAD bytes): unused LDS per fused workgroup = fewer resident workgroups per CU
     int roles_slots = 2;        // hand-off slots per env of the role-specialised kernel (DCC_ROLES_SLOTS = 2 / 4 / 8: A/B)
     int roles_pairs_forced = 0; // DCC_ROLES_PAIRS = 1 / 2 (A/B); 0 = by batch size
     int obs_drain_forced = -2;  // DCC_OBS_DRAIN = -1 / 0 / 2 (A/B); -2 = the default (2)
@@ -1588,7 +1589,7 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)env->lds_bytes));
     }
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), env->lds_bytes, s, p);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), env->lds_bytes + env->fused_lds_pad, s, p);
     HIP_TRY(hipGetLastError());
     return DCC_OK;
 }
@@ -1814,6 +1815,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     { const char* fs = std::getenv("DCC_FORCE_SPLIT"); e->force_split = fs && fs[0] == '1'; }
     { const char* re = std::getenv("DCC_ROLES_ENVS"); if (re && (re[0] == '1' || re[0] == '2')) e->roles_envs_forced = re[0] - '0'; }
     { const char* rm = std::getenv("DCC_ROLES1_MAX"); if (rm) e->roles1_max = std::atoi(rm); }
+    { const char* fp = std::getenv("DCC_FUSED_LDS_PAD"); if (fp) e->fused_lds_pad = (size_t)std::atoi(fp); }
     { const char* rp = std::getenv("DCC_ROLES_PAIRS"); if (rp && (rp[0] == '1' || rp[0] == '2')) e->roles_pairs_forced = rp[0] - '0'; }
     { const char* od = std::getenv("DCC_OBS_DRAIN"); if (od && od[0]) e->obs_drain_forced = std::atoi(od); }
     // hand-off depth: 8 slots per env while they are small (N <= 16: <= 1.1 KB each), else the minimum of 2.  Measured at c2 (profiles/r06/
