@@ -1431,7 +1431,8 @@ struct dcc_env {
     int roles1_max = 1600;      // batches up to this many envs run one env per (physics, observation) wave pair (DCC_ROLES1_MAX); measured
                                 // crossover on MI355X between 1536 (one env per pair +7 %) and 1792 (two envs +4 %): profiles/r06/small_batch_shapes.txt
     int n_cus = 256;            // compute units of the device (launch-shape policy only)
-    size_t fused_lds_pad = 0;   // experiment (DCC_FUSED_LDS_PAD bytes): unused LDS per fused workgroup = fewer resident workgroups per CU
+    long fused_lds_pad = -1;    // DCC_FUSED_LDS_PAD (bytes of unused LDS per fused workgroup, A/B); < 0 = the residency policy of launch()
+    size_t lds_two_per_cu = 0;  // LDS per workgroup above which at most two workgroups fit a CU (0: unknown -> no cap)
     int roles_slots = 2;        // hand-off slots per env of the role-specialised kernel (DCC_ROLES_SLOTS = 2 / 4 / 8: A/B)
     int roles_pairs_forced = 0; // DCC_ROLES_PAIRS = 1 / 2 (A/B); 0 = by batch size
     int obs_drain_forced = -2;  // DCC_OBS_DRAIN = -1 / 0 / 2 (A/B); -2 = the default (2)
@@ -1589,7 +1590,14 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)env->lds_bytes));
     }
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), env->lds_bytes + env->fused_lds_pad, s, p);
+    // Row-writing multi-step launches of the many-PoI shapes stream best with about two 4-wave workgroups (8 writer waves) resident per
+    // CU -- the c4 leg (16 x 256 x 8192 envs) 0.762 -> 0.787 of 8 TB/s with two instead of four, three change nothing, c5 is there by its
+    // registers (profiles/r06/small_batch_shapes.txt): unused LDS caps the residency.  Single steps (latency-bound) and grids that fit
+    // in two workgroups per CU anyway are left alone; DCC_FUSED_LDS_PAD=<bytes> (A/B) replaces the policy.
+    size_t lds = env->lds_bytes;
+    if (env->fused_lds_pad >= 0) lds += (size_t)env->fused_lds_pad;
+    else if (p.obs != nullptr && p.K >= 2 && env->PPL > 1 && grid > 2 * env->n_cus && lds < env->lds_two_per_cu) lds = env->lds_two_per_cu;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, s, p);
     HIP_TRY(hipGetLastError());
     return DCC_OK;
 }
@@ -1779,6 +1787,15 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     e->cfg.poi_xy = nullptr;
     e->device = dev;
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) e->n_cus = cus; else (void)hipGetLastError(); }
+    {   // LDS of a CU -> the smallest workgroup allocation of which only two fit (must stay within the 64 KB a launch may ask for)
+        int lds_cu = 0;
+        if (hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && lds_cu >= 96 * 1024) {
+            const size_t third = (size_t)lds_cu / 3 + 1024;
+            if (third <= 64 * 1024) e->lds_two_per_cu = (third + 255) & ~(size_t)255;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     const int E = c->n_envs, N = c->n_agents, M = c->n_pois;
     e->D = 4 + 2 * (N - 1) + 5 * M;
     e->L = N * e->D;
@@ -1815,7 +1832,7 @@ int dcc_env_create(const dcc_env_cfg* c, dcc_env** out) {
     { const char* fs = std::getenv("DCC_FORCE_SPLIT"); e->force_split = fs && fs[0] == '1'; }
     { const char* re = std::getenv("DCC_ROLES_ENVS"); if (re && (re[0] == '1' || re[0] == '2')) e->roles_envs_forced = re[0] - '0'; }
     { const char* rm = std::getenv("DCC_ROLES1_MAX"); if (rm) e->roles1_max = std::atoi(rm); }
-    { const char* fp = std::getenv("DCC_FUSED_LDS_PAD"); if (fp) e->fused_lds_pad = (size_t)std::atoi(fp); }
+    { const char* fp = std::getenv("DCC_FUSED_LDS_PAD"); if (fp && fp[0]) e->fused_lds_pad = std::atol(fp); }
     { const char* rp = std::getenv("DCC_ROLES_PAIRS"); if (rp && (rp[0] == '1' || rp[0] == '2')) e->roles_pairs_forced = rp[0] - '0'; }
     { const char* od = std::getenv("DCC_OBS_DRAIN"); if (od && od[0]) e->obs_drain_forced = std::atoi(od); }
     // hand-off depth: 8 slots per env while they are small (N <= 16: <= 1.1 KB each), else the minimum of 2.  Measured at c2 (profiles/r06/

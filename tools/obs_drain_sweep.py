@@ -62,7 +62,7 @@ elif SHAPE == "small":
         case(E, 1 if E <= 1024 else 2, False)
 elif SHAPE == "c4":
     N, M, T = 16, 256, 30
-    for E in (1024, 8192):
+    for E in (int(v) for v in os.environ.get("SWEEP_ES", "1024,3584,4096,6144,8192").split(",")):
         case(E, 2, False)
 elif SHAPE == "c5":
     N, M, T, CFS, RCOMM = 32, 1024, 4, 0.5, 0.1
