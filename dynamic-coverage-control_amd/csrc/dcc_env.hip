@@ -1590,13 +1590,13 @@ int launch(dcc_env* env, KParams& p, int act, void* stream) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)env->lds_bytes));
     }
-    // Row-writing multi-step launches of the many-PoI shapes stream best with about two 4-wave workgroups (8 writer waves) resident per
-    // CU -- the c4 leg (16 x 256 x 8192 envs) 0.762 -> 0.787 of 8 TB/s with two instead of four, three change nothing, c5 is there by its
+    // Row-writing multi-step launches stream best with about two 4-wave workgroups (8 writer waves) resident per CU -- c2 through this kernel
+    // (DCC_NO_ROLES / a create-time choice of the fused shape) 0.726 -> 0.770 at 4096 envs, the c4 leg (16 x 256 x 8192 envs) 0.762 -> 0.787 of 8 TB/s with two instead of four, three change nothing, c5 is there by its
     // registers (profiles/r06/small_batch_shapes.txt): unused LDS caps the residency.  Single steps (latency-bound) and grids that fit
     // in two workgroups per CU anyway are left alone; DCC_FUSED_LDS_PAD=<bytes> (A/B) replaces the policy.
     size_t lds = env->lds_bytes;
     if (env->fused_lds_pad >= 0) lds += (size_t)env->fused_lds_pad;
-    else if (p.obs != nullptr && p.K >= 2 && env->PPL > 1 && grid > 2 * env->n_cus && lds < env->lds_two_per_cu) lds = env->lds_two_per_cu;
+    else if (p.obs != nullptr && p.K >= 2 && grid > 2 * env->n_cus && lds < env->lds_two_per_cu) lds = env->lds_two_per_cu;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, s, p);
     HIP_TRY(hipGetLastError());
     return DCC_OK;
