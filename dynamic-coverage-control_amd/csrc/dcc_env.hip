@@ -1446,7 +1446,8 @@ struct dcc_env {
 namespace {
 
 typedef void (*kernel_fn)(const KParams);
-constexpr int kSplitMaxEnvs = 3072;   // above this the fused kernel has >= 3 waves per SIMD of its own
+constexpr int kSplitMaxEnvs = 1280;   // above this the fused kernel (two workgroups resident per CU) streams as fast or faster: 16 x 256, split vs fused at
+                                      // 1024 / 1536 / 2048 / 3072 envs 0.718 / 0.632 / 0.724 / 0.674 vs 0.665 / 0.651 / 0.733 / 0.680 (round 6; it was 3072)
 
 template <int ACT, bool FORCE>
 kernel_fn pick_ppl(int ppl) {
